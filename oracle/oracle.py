@@ -1,0 +1,260 @@
+"""ctypes binding of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product (pathtracer_amd) never does.  The shared object is built by oracle/Makefile
+(``make -C oracle``) from oracle/pt_oracle.c.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+class OrcScene(C.Structure):
+    _fields_ = [
+        ("n_tris", C.c_int32), ("verts", C.c_void_p), ("normals", C.c_void_p),
+        ("mat_ids", C.c_void_p), ("n_mats", C.c_int32), ("mats", C.c_void_p),
+        ("n_lights", C.c_int32), ("lights", C.c_void_p),
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("fov_deg", C.c_double), ("near_", C.c_double),
+        ("view", C.c_double * 16), ("cam_pos", C.c_double * 3),
+        ("depth", C.c_int32), ("spp", C.c_int32),
+        ("enable_indirect", C.c_int32), ("enable_bary_normal", C.c_int32),
+        ("region", C.c_int32 * 4), ("seed", C.c_uint64),
+        ("sample_offset", C.c_int32), ("spp_total", C.c_int32), ("use_bvh", C.c_int32),
+    ]
+
+
+class OrcStats(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("closest_rays", C.c_uint64),
+                ("shadow_rays", C.c_uint64), ("tri_tests", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError("oracle/liboracle.so missing: run `make -C oracle`")
+        L = C.CDLL(_LIB_PATH)
+        L.orc_rng.restype = C.c_double
+        L.orc_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_rng_bits.restype = C.c_uint64
+        L.orc_rng_bits.argtypes = L.orc_rng.argtypes
+        L.orc_tri_raycast.restype = C.c_int
+        L.orc_tri_raycast_t.restype = C.c_double
+        L.orc_closest_hit.restype = C.c_int32
+        L.orc_vistest.restype = C.c_int
+        L.orc_square_light_sample.restype = C.c_double
+        L.orc_square_light_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                              C.c_void_p, C.c_void_p]
+        L.orc_sphere_light_sample.restype = C.c_double
+        L.orc_sphere_light_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                              C.c_double, C.c_void_p, C.c_void_p]
+        L.orc_sample_hemisphere.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.orc_refract.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        L.orc_is_bsdf.restype = C.c_int
+        L.orc_num_threads.restype = C.c_int
+        L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_finalize.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _v3(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1)[:3])
+
+
+class Oracle:
+    """Holds a scene in the layout pt_oracle.c expects and exposes its entry points."""
+
+    def __init__(self, scene, seed=13, use_bvh=None):
+        self.scene = scene
+        self._keep = dict(
+            verts=np.ascontiguousarray(scene.verts, dtype=np.float64),
+            normals=np.ascontiguousarray(scene.normals, dtype=np.float64),
+            mat_ids=np.ascontiguousarray(scene.mat_ids, dtype=np.int32),
+            mats=np.ascontiguousarray(scene.mats, dtype=np.float64),
+            lights=np.ascontiguousarray(scene.lights, dtype=np.float64),
+        )
+        k = self._keep
+        s = OrcScene()
+        s.n_tris = k["verts"].shape[0]
+        s.verts, s.normals, s.mat_ids = _p(k["verts"]), _p(k["normals"]), _p(k["mat_ids"])
+        s.n_mats, s.mats = k["mats"].shape[0], _p(k["mats"])
+        s.n_lights, s.lights = k["lights"].shape[0], _p(k["lights"])
+        s.width, s.height = scene.width, scene.height
+        s.fov_deg, s.near_ = scene.fov_deg, scene.near
+        s.view = (C.c_double * 16)(*np.asarray(scene.view, dtype=np.float64).reshape(-1))
+        s.cam_pos = (C.c_double * 3)(*np.asarray(scene.cam_pos, dtype=np.float64).reshape(-1)[:3])
+        s.depth, s.spp = scene.depth, scene.spp
+        s.enable_indirect = int(scene.enable_indirect)
+        s.enable_bary_normal = int(scene.enable_bary_normal)
+        s.region = (C.c_int32 * 4)(*scene.region)
+        s.seed = seed
+        s.sample_offset = 0
+        s.spp_total = scene.spp
+        if use_bvh is None:
+            use_bvh = s.n_tris > 256
+        s.use_bvh = int(bool(use_bvh))
+        self.c = s
+        if s.use_bvh:
+            lib().orc_bvh_build(C.byref(s))
+
+    # -- geometry ------------------------------------------------------------------------------
+    def generate_rays(self):
+        n = self.c.width * self.c.height
+        o = np.zeros((n, 3))
+        d = np.zeros((n, 3))
+        lib().orc_generate_rays(C.byref(self.c), _p(o), _p(d))
+        return o, d
+
+    def camera_matrix(self):
+        m = np.zeros(16)
+        lib().orc_camera_matrix(C.byref(self.c), _p(m))
+        return m.reshape(4, 4)
+
+    def first_hit(self, with_points=False):
+        n = self.c.width * self.c.height
+        ids = np.zeros(n, dtype=np.int32)
+        pts = np.zeros((n, 3)) if with_points else None
+        lib().orc_first_hit(C.byref(self.c), _p(ids), _p(pts) if with_points else None)
+        return (ids, pts) if with_points else ids
+
+    def closest_hit(self, o, d):
+        o, d = _v3(o), _v3(d)
+        pt = np.zeros(3)
+        f = lib().orc_closest_hit(C.byref(self.c), _p(o), _p(d), _p(pt))
+        return int(f), pt
+
+    def vistest(self, p1, p2):
+        p1, p2 = _v3(p1), _v3(p2)
+        return bool(lib().orc_vistest(C.byref(self.c), _p(p1), _p(p2)))
+
+    # -- render --------------------------------------------------------------------------------
+    def render(self, spp=None, sample_offset=0, spp_total=None, threads=0, stats=False):
+        """Returns the pre-final-clamp sums [H,W,3] (and stats when asked)."""
+        c = self.c
+        if spp is not None:
+            c.spp = int(spp)
+        c.sample_offset = int(sample_offset)
+        c.spp_total = int(spp_total) if spp_total is not None else c.spp
+        out = np.zeros((c.height, c.width, 3))
+        st = OrcStats()
+        lib().orc_render(C.byref(c), _p(out), C.byref(st) if stats else None, int(threads))
+        if stats:
+            return out, {f[0]: int(getattr(st, f[0])) for f in OrcStats._fields_}
+        return out
+
+
+def finalize(img_sum):
+    a = np.ascontiguousarray(img_sum, dtype=np.float64)
+    out = np.zeros_like(a)
+    lib().orc_finalize(_p(a), _p(out), a.size // 3)
+    return out
+
+
+# -- free functions with explicit inputs (known-answer tests) ----------------------------------
+def rng(seed, pixel, sample, bounce, dim):
+    return lib().orc_rng(seed, pixel, sample, bounce, dim)
+
+
+def tri_raycast(o, d, p1, p2, p3):
+    o, d, p1, p2, p3 = map(_v3, (o, d, p1, p2, p3))
+    pt = np.zeros(3)
+    ok = lib().orc_tri_raycast(_p(o), _p(d), _p(p1), _p(p2), _p(p3), _p(pt))
+    return bool(ok), pt
+
+
+def tri_raycast_t(o, d, p1, p2, p3):
+    o, d, p1, p2, p3 = map(_v3, (o, d, p1, p2, p3))
+    return lib().orc_tri_raycast_t(_p(o), _p(d), _p(p1), _p(p2), _p(p3))
+
+
+def reflect(n, i):
+    n, i = _v3(n), _v3(i)
+    o = np.zeros(3)
+    lib().orc_reflect(_p(n), _p(i), _p(o))
+    return o
+
+
+def refract(n, i, ni):
+    n, i = _v3(n), _v3(i)
+    o = np.zeros(3)
+    lib().orc_refract(_p(n), _p(i), float(ni), _p(o))
+    return o
+
+
+def barycentric(p, a, b, c):
+    p, a, b, c = map(_v3, (p, a, b, c))
+    w = np.zeros(3)
+    lib().orc_barycentric(_p(p), _p(a), _p(b), _p(c), _p(w))
+    return w
+
+
+def normal_from_3pts(a, b, c):
+    a, b, c = map(_v3, (a, b, c))
+    n = np.zeros(3)
+    lib().orc_normal_from_3pts(_p(a), _p(b), _p(c), _p(n))
+    return n
+
+
+def sample_hemisphere(n, xi1, xi2):
+    n = _v3(n)
+    o = np.zeros(3)
+    lib().orc_sample_hemisphere(_p(n), float(xi1), float(xi2), _p(o))
+    return o
+
+
+def square_light_sample(light16, ref, xi1, xi2):
+    L = np.ascontiguousarray(light16, dtype=np.float64)
+    ref = _v3(ref)
+    ro, rd = np.zeros(3), np.zeros(3)
+    pdf = lib().orc_square_light_sample(_p(L), _p(ref), float(xi1), float(xi2), _p(ro), _p(rd))
+    return pdf, ro, rd
+
+
+def sphere_light_sample(light16, ref, xi1, xi2, xi3):
+    L = np.ascontiguousarray(light16, dtype=np.float64)
+    ref = _v3(ref)
+    ro, rd = np.zeros(3), np.zeros(3)
+    pdf = lib().orc_sphere_light_sample(_p(L), _p(ref), float(xi1), float(xi2), float(xi3),
+                                        _p(ro), _p(rd))
+    return pdf, ro, rd
+
+
+def bxdf_eval(mat12, wi, wo, n):
+    m = np.ascontiguousarray(mat12, dtype=np.float64)
+    wi, wo, n = map(_v3, (wi, wo, n))
+    f = np.zeros(3)
+    lib().orc_bxdf_eval(_p(m), _p(wi), _p(wo), _p(n), _p(f))
+    return f
+
+
+def bxdf_sample(mat12, n, wo, xi):
+    m = np.ascontiguousarray(mat12, dtype=np.float64)
+    n, wo = _v3(n), _v3(wo)
+    x = np.ascontiguousarray(np.asarray(xi, dtype=np.float64).reshape(-1)[:2])
+    if x.size < 2:
+        x = np.concatenate([x, np.zeros(2 - x.size)])
+    wi, coef = np.zeros(3), np.zeros(3)
+    lib().orc_bxdf_sample(_p(m), _p(n), _p(wo), _p(x), _p(wi), _p(coef))
+    return wi, coef
+
+
+def rmse_rel(a, b):
+    """Per-pixel relative MSE  mean_p sum_c (a-b)^2 / (b^2 + 1e-2)  on linear float images."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.mean(np.sum((a - b) ** 2 / (b ** 2 + 1e-2), axis=-1)))
