@@ -1,0 +1,157 @@
+/*
+ * ptx.h -- C ABI of the MI355X path-tracing core (libptx_amd.so).
+ *
+ * The reference (Rullec/PathTracer) has no plugin/FFI interface; the boundary this library sits
+ * behind is the C++ class surface between its scene layer and its tracer.  Every entry point below
+ * cites the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions: plain C, opaque handles, int status returns (0 = PTX_OK), no exceptions cross the
+ * boundary, caller-owned output buffers, one context per host thread / GPU.  After a non-zero
+ * return ptx_last_error() describes the failure (thread-local).
+ */
+#ifndef PTX_H
+#define PTX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTX_OK 0
+#define PTX_ERR_ARG 1      /* bad argument / null pointer                                       */
+#define PTX_ERR_IO 2       /* file missing or unreadable                                        */
+#define PTX_ERR_PARSE 3    /* malformed conf / OBJ / MTL                                        */
+#define PTX_ERR_DEVICE 4   /* HIP error (no device, allocation, launch)                         */
+#define PTX_ERR_STATE 5    /* call order violated (e.g. render before build_accel)              */
+
+#define PTX_MODE_F64 0 /* reference arithmetic: double everywhere, no FMA contraction           */
+#define PTX_MODE_F32 1 /* fast path: float state and tests, statistically equivalent images     */
+
+typedef struct ptx_scene ptx_scene;
+typedef struct ptx_context ptx_context;
+
+/* Overrides of conf values (the benchmark configs change W/H/spp relative to the shipped confs).
+ * A field <= 0 (or NULL) keeps the conf's value. */
+typedef struct ptx_overrides
+{
+    int32_t width, height, spp, depth;
+    const char *model;     /* replaces Scene.ModelName                                           */
+    int32_t full_region;   /* != 0: DrawRegion := [0,0,H,W]                                      */
+} ptx_overrides;
+
+typedef struct ptx_scene_info
+{
+    int32_t n_tris, n_mats, n_lights, n_square_lights;
+    int32_t width, height, depth, spp;
+    int32_t enable_indirect, enable_bary_normal, enable_path_tracing;
+    int32_t region[4];     /* stRow, stCol, edRow, edCol (inclusive)                             */
+    int32_t accel_type;    /* 0 None, 1 AABB, 2 OCTREE (accepted for compatibility; the core always
+                              uses its own BVH / brute-force intersector)                        */
+    double fov_deg, near_plane, world_scale;
+} ptx_scene_info;
+
+typedef struct ptx_render_opts
+{
+    int32_t mode;          /* PTX_MODE_F64 | PTX_MODE_F32                                        */
+    int32_t spp;           /* samples rendered by this call (<=0: scene spp)                     */
+    int32_t sample_offset; /* global index of the first sample (sample-range sharding)           */
+    int32_t spp_total;     /* divisor of the per-sample average (<=0: spp)                       */
+    int32_t row_begin, row_end; /* rows [row_begin,row_end) rendered by this call; 0,0 = all     */
+    int32_t row_stride, row_phase, band; /* interleaved bands: a row r is rendered iff
+                              ((r / band) % row_stride) == row_phase; stride<=1 disables          */
+    int32_t depth;         /* <=0: scene depth                                                   */
+    uint64_t seed;         /* RNG seed (the reference's srand(13) -> default 13)                 */
+    int64_t batch_paths;   /* paths in flight per pass (<=0: library default)                    */
+    int32_t accumulate;    /* != 0: add to the sums already in the output buffer                 */
+    int32_t profile;       /* != 0: time every kernel class with HIP events (slower; fills ms_*)  */
+} ptx_render_opts;
+
+typedef struct ptx_stats
+{
+    uint64_t paths;         /* pixel-samples traced                                              */
+    uint64_t segments;      /* closest-hit rays (one per bounce of every path)                   */
+    uint64_t shadow_rays;   /* visibility tests issued                                           */
+    uint64_t passes;        /* wavefront batches                                                 */
+    double ms_total;        /* device time of the call, HIP events on the context's stream       */
+    double ms_extend, ms_shade, ms_shadow, ms_other; /* per-kernel-class device time (profiling
+                               mode only, otherwise 0)                                           */
+} ptx_stats;
+
+/* ---- scene front end ----------------------------------------------------------------------
+ * Replaces cRTScene::cRTScene + cRTScene::Init's mesh load (src/scene/cRTScene.cpp:6-39),
+ * cMeshLoader::LoadObj (src/geometry/cMeshLoader.cpp:48-201), cBaseCamera::ParseConf / Reload
+ * (src/render/camera/cBaseCamera.cpp:57-90,132-156), cPathTracer::ParseConfig
+ * (src/tracing/cPathTracer.cpp:215-259) and BuildLight (src/tracing/cLight.cpp:266-358).
+ * root_dir: directory the conf's relative paths are resolved against (the reference is run from
+ * its repository root, src/main.cpp:30-32); NULL = current directory. */
+int ptx_scene_load_conf(const char *conf_path, const char *root_dir, const ptx_overrides *ov,
+                        ptx_scene **out);
+
+/* Scene from caller arrays (no files).  verts/normals: [n_tris][3][3] float; mats: [n_mats][12]
+ * double (Ka Kd Ks Ni Ns illum); lights: [n_lights][16] double (type Li[3] then 4 corners or
+ * centre+radius); view16: row-major view matrix; replaces the same reference code as above. */
+int ptx_scene_from_arrays(const float *verts, const float *normals, const int32_t *mat_ids,
+                          int32_t n_tris, const double *mats, int32_t n_mats,
+                          const double *lights, int32_t n_lights, const double *view16,
+                          const double *cam_pos3, double fov_deg, double near_plane,
+                          int32_t width, int32_t height, int32_t depth, int32_t spp,
+                          int32_t enable_indirect, int32_t enable_bary_normal, ptx_scene **out);
+void ptx_scene_destroy(ptx_scene *);
+
+/* Introspection (what cObjMesh::GetFaceList / GetMaterial / cBaseCamera::GetViewMat expose,
+ * src/geometry/cObjMesh.h, src/render/camera/cBaseCamera.hpp:26-31). Null outputs are skipped. */
+int ptx_scene_get_info(const ptx_scene *, ptx_scene_info *out);
+int ptx_scene_copy_geometry(const ptx_scene *, float *verts, float *normals, int32_t *mat_ids);
+int ptx_scene_copy_tables(const ptx_scene *, double *mats12, double *lights16);
+int ptx_scene_copy_camera(const ptx_scene *, double *view16, double *cam_pos3, double *raster2world16);
+const char *ptx_scene_result_path(const ptx_scene *);
+
+/* ---- context / accel -------------------------------------------------------------------------
+ * ptx_context_create + ptx_build_accel replace cPathTracer::Init (src/tracing/cPathTracer.cpp:20-57)
+ * and cAccelStruct::Init (src/geometry/cAccelStruct.cpp:16-26, 95-179, 377-482).
+ * hip_stream: a hipStream_t (NULL = the device's default stream). */
+int ptx_context_create(int32_t hip_device, ptx_context **out);
+int ptx_context_set_stream(ptx_context *, void *hip_stream);
+void ptx_context_destroy(ptx_context *);
+/* Tunables: "brute_force_limit" (scenes with at most this many triangles use the all-triangles
+ * loop instead of the BVH; default 64), "default_batch_paths".  Set before ptx_build_accel. */
+int ptx_context_set_option(ptx_context *, const char *name, int64_t value);
+int ptx_build_accel(ptx_context *, const ptx_scene *);
+/* BVH statistics of the last build: n_nodes, n_leaves, max_depth, max_leaf_tris, brute_force flag */
+int ptx_accel_info(const ptx_context *, int32_t *info5);
+
+/* ---- hot path ----------------------------------------------------------------------------------
+ * ptx_generate_rays  replaces cPathTracer::GenerateRay (src/tracing/cPathTracer.cpp:129-213):
+ *                    origins/directions [H*W][3] double, HOST buffers.
+ * ptx_first_hit      replaces cAccelStruct::RayCast for the camera rays
+ *                    (src/geometry/cAccelStruct.cpp:28-54): face id per pixel, -1 = miss; HOST
+ *                    buffers; hit_pts may be NULL.
+ * ptx_render         replaces cPathTracer::Process / RayTracing / RayTracePrimaryRay
+ *                    (src/tracing/cPathTracer.cpp:65-86, 517-704): writes the per-pixel sums
+ *                    sum_s final_s / spp_total BEFORE the last max-clamp, [H*W][3] double.
+ *                    out_is_device != 0: rgb_sum is device memory on the context's GPU.
+ * ptx_raycast / ptx_vistest  batched operator forms of cAccelStruct::RayCast / VisTest
+ *                    (src/geometry/cAccelStruct.hpp:33-35) on HOST arrays of n rays / segments. */
+int ptx_generate_rays(ptx_context *, double *rays_o, double *rays_d);
+int ptx_first_hit(ptx_context *, int32_t *face_ids, double *hit_pts);
+int ptx_render(ptx_context *, const ptx_render_opts *, double *rgb_sum, int32_t out_is_device,
+               ptx_stats *stats);
+int ptx_raycast(ptx_context *, const double *rays_o, const double *rays_d, int64_t n,
+                int32_t *face_ids, double *hit_pts);
+int ptx_vistest(ptx_context *, const double *p1, const double *p2, int64_t n, int32_t *visible);
+
+/* ---- image output --------------------------------------------------------------------------
+ * ptx_finalize_image: the last per-pixel max-clamp (src/tracing/cPathTracer.cpp:701-702), host.
+ * ptx_write_ppm: cPathTracer::OutputImage (src/tracing/cPathTracer.cpp:261-284): "P3\nW H\n255\n"
+ * then int(c*255) triplets separated by single spaces on one line. */
+int ptx_finalize_image(const double *rgb_sum, int64_t n_pixels, double *rgb_out);
+int ptx_write_ppm(const char *path, const double *rgb, int32_t width, int32_t height);
+
+const char *ptx_last_error(void);
+const char *ptx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTX_H */

@@ -1,0 +1,256 @@
+// Binned-SAH BVH builder (host).  Replaces the reference's accel builders
+// (src/geometry/cAccelStruct.cpp:95-179 uniform grid, :291-482 octree) with a structure laid out
+// for the GPU; hit semantics stay those of the brute-force loops (src/geometry/cAccelStruct.cpp:28-87).
+#include "bvh.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace ptx
+{
+
+namespace
+{
+
+struct Box
+{
+    double lo[3], hi[3];
+    Box()
+    {
+        for (int k = 0; k < 3; k++)
+            lo[k] = std::numeric_limits<double>::infinity(), hi[k] = -std::numeric_limits<double>::infinity();
+    }
+    void grow(const double *p)
+    {
+        for (int k = 0; k < 3; k++)
+        {
+            lo[k] = std::min(lo[k], p[k]);
+            hi[k] = std::max(hi[k], p[k]);
+        }
+    }
+    void grow(const Box &b)
+    {
+        for (int k = 0; k < 3; k++)
+        {
+            lo[k] = std::min(lo[k], b.lo[k]);
+            hi[k] = std::max(hi[k], b.hi[k]);
+        }
+    }
+    double area() const
+    {
+        double e0 = hi[0] - lo[0], e1 = hi[1] - lo[1], e2 = hi[2] - lo[2];
+        if (e0 < 0)
+            return 0;
+        return 2 * (e0 * e1 + e1 * e2 + e2 * e0);
+    }
+};
+
+struct Builder
+{
+    const float *verts;
+    std::vector<Box> tri_box;
+    std::vector<double> centroid; // [F][3]
+    std::vector<int32_t> order;
+    std::vector<BvhNode> nodes;
+    int max_leaf, n_leaves = 0, max_depth = 0, max_leaf_seen = 0;
+    double pad_abs;
+
+    Box range_box(int first, int count) const
+    {
+        Box b;
+        for (int i = first; i < first + count; i++)
+            b.grow(tri_box[order[i]]);
+        return b;
+    }
+
+    void store_box(const Box &b, float *lo, float *hi) const
+    {
+        for (int k = 0; k < 3; k++)
+        {
+            double l = b.lo[k] - pad_abs, h = b.hi[k] + pad_abs;
+            float fl = static_cast<float>(l), fh = static_cast<float>(h);
+            if (static_cast<double>(fl) > l)
+                fl = std::nextafter(fl, -std::numeric_limits<float>::infinity());
+            if (static_cast<double>(fh) < h)
+                fh = std::nextafter(fh, std::numeric_limits<float>::infinity());
+            lo[k] = fl, hi[k] = fh;
+        }
+    }
+
+    // returns child reference (node index or encoded leaf)
+    int32_t build(int first, int count, int depth)
+    {
+        max_depth = std::max(max_depth, depth);
+        if (count <= max_leaf)
+            return make_leaf(first, count);
+
+        Box cb;
+        for (int i = first; i < first + count; i++)
+            cb.grow(&centroid[order[i] * 3]);
+        int axis = 0;
+        double ext = cb.hi[0] - cb.lo[0];
+        for (int k = 1; k < 3; k++)
+            if (cb.hi[k] - cb.lo[k] > ext)
+                ext = cb.hi[k] - cb.lo[k], axis = k;
+
+        int mid = first + count / 2;
+        if (ext > 0)
+        {
+            constexpr int NB = 16;
+            Box bb[NB];
+            int bc[NB] = {0};
+            const double k1 = NB * (1 - 1e-9) / ext;
+            for (int i = first; i < first + count; i++)
+            {
+                int b = static_cast<int>((centroid[order[i] * 3 + axis] - cb.lo[axis]) * k1);
+                b = std::min(std::max(b, 0), NB - 1);
+                bb[b].grow(tri_box[order[i]]);
+                bc[b]++;
+            }
+            double left_area[NB], right_area[NB];
+            int left_cnt[NB], right_cnt[NB];
+            Box acc;
+            int c = 0;
+            for (int b = 0; b < NB; b++)
+            {
+                acc.grow(bb[b]);
+                c += bc[b];
+                left_area[b] = acc.area(), left_cnt[b] = c;
+            }
+            acc = Box();
+            c = 0;
+            for (int b = NB - 1; b >= 0; b--)
+            {
+                acc.grow(bb[b]);
+                c += bc[b];
+                right_area[b] = acc.area(), right_cnt[b] = c;
+            }
+            double best = std::numeric_limits<double>::infinity();
+            int best_b = -1;
+            for (int b = 0; b < NB - 1; b++)
+            {
+                if (left_cnt[b] == 0 || right_cnt[b + 1] == 0)
+                    continue;
+                double cost = left_area[b] * left_cnt[b] + right_area[b + 1] * right_cnt[b + 1];
+                if (cost < best)
+                    best = cost, best_b = b;
+            }
+            if (best_b >= 0)
+            {
+                const double lo = cb.lo[axis];
+                auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](int32_t t) {
+                    int b = static_cast<int>((centroid[t * 3 + axis] - lo) * k1);
+                    b = std::min(std::max(b, 0), NB - 1);
+                    return b <= best_b;
+                });
+                mid = static_cast<int>(it - order.begin());
+            }
+        }
+        if (mid <= first || mid >= first + count)
+        {
+            // degenerate (all centroids equal): split by index
+            mid = first + count / 2;
+            if (count <= 8)
+                return make_leaf(first, count);
+        }
+        int32_t me = static_cast<int32_t>(nodes.size());
+        nodes.emplace_back();
+        Box b0 = range_box(first, mid - first), b1 = range_box(mid, first + count - mid);
+        int32_t c0 = build(first, mid - first, depth + 1);
+        int32_t c1 = build(mid, first + count - mid, depth + 1);
+        BvhNode &nd = nodes[me];
+        store_box(b0, nd.lo0, nd.hi0);
+        store_box(b1, nd.lo1, nd.hi1);
+        nd.c0 = c0, nd.c1 = c1;
+        nd.pad[0] = nd.pad[1] = 0;
+        return me;
+    }
+
+    int32_t make_leaf(int first, int count)
+    {
+        // leaves hold at most 8 triangles; larger degenerate groups are chained through nodes
+        if (count > 8)
+        {
+            int32_t me = static_cast<int32_t>(nodes.size());
+            nodes.emplace_back();
+            int half = count / 2;
+            Box b0 = range_box(first, half), b1 = range_box(first + half, count - half);
+            int32_t c0 = make_leaf(first, half), c1 = make_leaf(first + half, count - half);
+            BvhNode &nd = nodes[me];
+            store_box(b0, nd.lo0, nd.hi0);
+            store_box(b1, nd.lo1, nd.hi1);
+            nd.c0 = c0, nd.c1 = c1;
+            nd.pad[0] = nd.pad[1] = 0;
+            return me;
+        }
+        n_leaves++;
+        max_leaf_seen = std::max(max_leaf_seen, count);
+        return ~static_cast<int32_t>((first << 3) | (count - 1));
+    }
+};
+
+} // namespace
+
+void build_bvh(const float *verts, int n_tris, Bvh &out, int max_leaf_tris)
+{
+    Builder B;
+    B.verts = verts;
+    B.max_leaf = std::min(std::max(max_leaf_tris, 1), 8);
+    B.tri_box.resize(n_tris);
+    B.centroid.resize(static_cast<size_t>(n_tris) * 3);
+    B.order.resize(n_tris);
+    double max_abs = 0;
+    for (int f = 0; f < n_tris; f++)
+    {
+        B.order[f] = f;
+        double c[3] = {0, 0, 0};
+        for (int j = 0; j < 3; j++)
+        {
+            double p[3];
+            for (int k = 0; k < 3; k++)
+            {
+                p[k] = verts[f * 9 + j * 3 + k];
+                c[k] += p[k];
+                max_abs = std::max(max_abs, std::fabs(p[k]));
+            }
+            B.tri_box[f].grow(p);
+        }
+        for (int k = 0; k < 3; k++)
+            B.centroid[f * 3 + k] = c[k] / 3.0;
+    }
+    B.pad_abs = 1e-6 * (1.0 + max_abs);
+
+    out = Bvh();
+    if (n_tris <= 0)
+    {
+        BvhNode nd;
+        std::memset(&nd, 0, sizeof(nd));
+        for (int k = 0; k < 3; k++) // boxes at +infinity: the slab test can never enter them
+            nd.lo0[k] = nd.lo1[k] = nd.hi0[k] = nd.hi1[k] = std::numeric_limits<float>::infinity();
+        nd.c0 = nd.c1 = ~0;
+        out.nodes.push_back(nd);
+        return;
+    }
+    int32_t root = B.build(0, n_tris, 0);
+    if (root < 0)
+    {
+        // whole scene fits one leaf: wrap it in a node whose second child is empty
+        BvhNode nd;
+        std::memset(&nd, 0, sizeof(nd));
+        B.store_box(B.range_box(0, n_tris), nd.lo0, nd.hi0);
+        for (int k = 0; k < 3; k++) // a box at +infinity: the slab test can never enter it
+            nd.lo1[k] = nd.hi1[k] = std::numeric_limits<float>::infinity();
+        nd.c0 = root;
+        nd.c1 = root; // never visited: its box is empty
+        B.nodes.push_back(nd);
+    }
+    out.nodes = std::move(B.nodes);
+    out.tri_order = std::move(B.order);
+    out.n_leaves = B.n_leaves;
+    out.max_depth = B.max_depth;
+    out.max_leaf = B.max_leaf_seen;
+}
+
+} // namespace ptx

@@ -1,0 +1,411 @@
+// extern "C" boundary of libptx_amd.so: translates exceptions into status codes, owns the handles.
+#include "../../include/ptx.h"
+#include "context.hpp"
+#include "scene.hpp"
+
+#include <cstring>
+#include <new>
+#include <stdexcept>
+#include <string>
+
+struct ptx_scene
+{
+    ptx::Scene sc;
+};
+struct ptx_context
+{
+    ptx::Context *ctx = nullptr;
+};
+
+namespace
+{
+thread_local std::string g_last_error;
+
+int fail(const std::exception &e)
+{
+    g_last_error = e.what();
+    const std::string &m = g_last_error;
+    if (m.rfind("io:", 0) == 0)
+        return PTX_ERR_IO;
+    if (m.rfind("parse:", 0) == 0 || m.rfind("json:", 0) == 0)
+        return PTX_ERR_PARSE;
+    if (m.rfind("device:", 0) == 0)
+        return PTX_ERR_DEVICE;
+    if (m.rfind("state:", 0) == 0)
+        return PTX_ERR_STATE;
+    return PTX_ERR_ARG;
+}
+int fail_arg(const char *what)
+{
+    g_last_error = std::string("arg: ") + what;
+    return PTX_ERR_ARG;
+}
+} // namespace
+
+#define PTX_TRY try {
+#define PTX_CATCH                                                                                        \
+    }                                                                                                    \
+    catch (const std::bad_alloc &)                                                                       \
+    {                                                                                                    \
+        g_last_error = "device: out of host memory";                                                     \
+        return PTX_ERR_DEVICE;                                                                           \
+    }                                                                                                    \
+    catch (const std::exception &e) { return fail(e); }                                                  \
+    catch (...)                                                                                          \
+    {                                                                                                    \
+        g_last_error = "unknown error";                                                                  \
+        return PTX_ERR_ARG;                                                                              \
+    }                                                                                                    \
+    return PTX_OK;
+
+extern "C" {
+
+const char *ptx_last_error(void) { return g_last_error.c_str(); }
+const char *ptx_version(void) { return "pathtracer_amd 0.1 (gfx950)"; }
+
+int ptx_scene_load_conf(const char *conf_path, const char *root_dir, const ptx_overrides *ov, ptx_scene **out)
+{
+    if (!conf_path || !out)
+        return fail_arg("ptx_scene_load_conf: null argument");
+    *out = nullptr;
+    PTX_TRY
+    ptx::Overrides o;
+    if (ov)
+    {
+        o.width = ov->width, o.height = ov->height, o.spp = ov->spp, o.depth = ov->depth;
+        if (ov->model)
+            o.model = ov->model;
+        o.full_region = ov->full_region != 0;
+    }
+    auto *s = new ptx_scene();
+    try
+    {
+        ptx::load_conf(conf_path, root_dir ? root_dir : "", o, s->sc);
+    }
+    catch (...)
+    {
+        delete s;
+        throw;
+    }
+    *out = s;
+    PTX_CATCH
+}
+
+int ptx_scene_from_arrays(const float *verts, const float *normals, const int32_t *mat_ids, int32_t n_tris,
+                          const double *mats, int32_t n_mats, const double *lights, int32_t n_lights,
+                          const double *view16, const double *cam_pos3, double fov_deg, double near_plane, int32_t width,
+                          int32_t height, int32_t depth, int32_t spp, int32_t enable_indirect, int32_t enable_bary_normal,
+                          ptx_scene **out)
+{
+    if (!out || n_tris < 0 || n_mats < 0 || n_lights < 0 || (n_tris > 0 && (!verts || !mat_ids)) || !view16 || !cam_pos3)
+        return fail_arg("ptx_scene_from_arrays: null or negative argument");
+    if (width <= 0 || height <= 0 || depth <= 0 || spp <= 0)
+        return fail_arg("ptx_scene_from_arrays: width, height, depth and spp must be positive");
+    *out = nullptr;
+    PTX_TRY
+    auto *s = new ptx_scene();
+    ptx::Scene &sc = s->sc;
+    sc.verts.assign(verts, verts + static_cast<size_t>(n_tris) * 9);
+    sc.has_normals = normals != nullptr;
+    if (normals)
+        sc.normals.assign(normals, normals + static_cast<size_t>(n_tris) * 9);
+    else
+        sc.normals.assign(static_cast<size_t>(n_tris) * 9, 0.f);
+    sc.mat_ids.assign(mat_ids, mat_ids + n_tris);
+    sc.vert_ids.assign(static_cast<size_t>(n_tris) * 3, -1);
+    for (int i = 0; i < n_tris; i++)
+        if (sc.mat_ids[i] >= n_mats)
+        {
+            delete s;
+            throw std::runtime_error("arg: material id out of range");
+        }
+    for (int i = 0; i < n_mats; i++)
+    {
+        ptx::Material m;
+        const double *p = mats + static_cast<size_t>(i) * 12;
+        for (int c = 0; c < 3; c++)
+            m.Ka[c] = p[c], m.Kd[c] = p[3 + c], m.Ks[c] = p[6 + c];
+        m.Ni = p[9], m.Ns = p[10], m.illum = p[11];
+        sc.mats.push_back(m);
+    }
+    for (int i = 0; i < n_lights; i++)
+    {
+        ptx::Light L;
+        const double *p = lights + static_cast<size_t>(i) * 16;
+        L.type = p[0] == 0.0 ? 0 : 1;
+        for (int c = 0; c < 3; c++)
+            L.radiance[c] = p[1 + c];
+        if (L.type == 0)
+        {
+            for (int k = 0; k < 4; k++)
+                for (int c = 0; c < 3; c++)
+                    L.p[k][c] = p[4 + 3 * k + c];
+        }
+        else
+        {
+            for (int c = 0; c < 3; c++)
+                L.center[c] = p[4 + c];
+            L.radius = p[7];
+        }
+        sc.lights.push_back(L);
+    }
+    std::memcpy(sc.view, view16, sizeof(double) * 16);
+    for (int c = 0; c < 3; c++)
+        sc.cam_pos[c] = cam_pos3[c];
+    sc.fov_deg = fov_deg, sc.near_plane = near_plane;
+    sc.width = width, sc.height = height, sc.depth = depth, sc.spp = spp;
+    sc.enable_indirect = enable_indirect != 0, sc.enable_bary_normal = enable_bary_normal != 0;
+    sc.region[0] = 0, sc.region[1] = 0, sc.region[2] = height, sc.region[3] = width;
+    sc.update_camera();
+    *out = s;
+    PTX_CATCH
+}
+
+void ptx_scene_destroy(ptx_scene *s) { delete s; }
+
+int ptx_scene_get_info(const ptx_scene *s, ptx_scene_info *o)
+{
+    if (!s || !o)
+        return fail_arg("ptx_scene_get_info: null argument");
+    const ptx::Scene &sc = s->sc;
+    o->n_tris = sc.n_tris(), o->n_mats = static_cast<int32_t>(sc.mats.size());
+    o->n_lights = static_cast<int32_t>(sc.lights.size()), o->n_square_lights = sc.n_square_lights();
+    o->width = sc.width, o->height = sc.height, o->depth = sc.depth, o->spp = sc.spp;
+    o->enable_indirect = sc.enable_indirect, o->enable_bary_normal = sc.enable_bary_normal;
+    o->enable_path_tracing = sc.enable_path_tracing;
+    for (int i = 0; i < 4; i++)
+        o->region[i] = sc.region[i];
+    o->accel_type = sc.accel_type;
+    o->fov_deg = sc.fov_deg, o->near_plane = sc.near_plane, o->world_scale = sc.world_scale;
+    return PTX_OK;
+}
+
+int ptx_scene_copy_geometry(const ptx_scene *s, float *verts, float *normals, int32_t *mat_ids)
+{
+    if (!s)
+        return fail_arg("ptx_scene_copy_geometry: null scene");
+    const ptx::Scene &sc = s->sc;
+    if (verts)
+        std::memcpy(verts, sc.verts.data(), sc.verts.size() * sizeof(float));
+    if (normals)
+        std::memcpy(normals, sc.normals.data(), sc.normals.size() * sizeof(float));
+    if (mat_ids)
+        std::memcpy(mat_ids, sc.mat_ids.data(), sc.mat_ids.size() * sizeof(int32_t));
+    return PTX_OK;
+}
+
+int ptx_scene_copy_tables(const ptx_scene *s, double *mats12, double *lights16)
+{
+    if (!s)
+        return fail_arg("ptx_scene_copy_tables: null scene");
+    const ptx::Scene &sc = s->sc;
+    if (mats12)
+        for (size_t i = 0; i < sc.mats.size(); i++)
+        {
+            double *p = mats12 + i * 12;
+            const ptx::Material &m = sc.mats[i];
+            for (int c = 0; c < 3; c++)
+                p[c] = m.Ka[c], p[3 + c] = m.Kd[c], p[6 + c] = m.Ks[c];
+            p[9] = m.Ni, p[10] = m.Ns, p[11] = m.illum;
+        }
+    if (lights16)
+        for (size_t i = 0; i < sc.lights.size(); i++)
+        {
+            double *p = lights16 + i * 16;
+            const ptx::Light &L = sc.lights[i];
+            std::memset(p, 0, sizeof(double) * 16);
+            p[0] = L.type;
+            for (int c = 0; c < 3; c++)
+                p[1 + c] = L.radiance[c];
+            if (L.type == 0)
+            {
+                for (int k = 0; k < 4; k++)
+                    for (int c = 0; c < 3; c++)
+                        p[4 + 3 * k + c] = L.p[k][c];
+            }
+            else
+            {
+                for (int c = 0; c < 3; c++)
+                    p[4 + c] = L.center[c];
+                p[7] = L.radius;
+            }
+        }
+    return PTX_OK;
+}
+
+int ptx_scene_copy_camera(const ptx_scene *s, double *view16, double *cam_pos3, double *raster2world16)
+{
+    if (!s)
+        return fail_arg("ptx_scene_copy_camera: null scene");
+    if (view16)
+        std::memcpy(view16, s->sc.view, sizeof(double) * 16);
+    if (cam_pos3)
+        std::memcpy(cam_pos3, s->sc.cam_pos, sizeof(double) * 3);
+    if (raster2world16)
+        std::memcpy(raster2world16, s->sc.raster2world, sizeof(double) * 16);
+    return PTX_OK;
+}
+
+const char *ptx_scene_result_path(const ptx_scene *s) { return s ? s->sc.result_path.c_str() : ""; }
+
+int ptx_context_create(int32_t hip_device, ptx_context **out)
+{
+    if (!out)
+        return fail_arg("ptx_context_create: null argument");
+    *out = nullptr;
+    PTX_TRY
+    auto *c = new ptx_context();
+    try
+    {
+        c->ctx = new ptx::Context(hip_device);
+    }
+    catch (...)
+    {
+        delete c;
+        throw;
+    }
+    *out = c;
+    PTX_CATCH
+}
+
+int ptx_context_set_stream(ptx_context *c, void *hip_stream)
+{
+    if (!c || !c->ctx)
+        return fail_arg("ptx_context_set_stream: null context");
+    c->ctx->set_stream(hip_stream);
+    return PTX_OK;
+}
+
+int ptx_context_set_option(ptx_context *c, const char *name, int64_t value)
+{
+    if (!c || !c->ctx || !name)
+        return fail_arg("ptx_context_set_option: null argument");
+    const std::string n = name;
+    if (n == "brute_force_limit")
+        c->ctx->brute_force_limit = static_cast<int>(value);
+    else if (n == "default_batch_paths" && value > 0)
+        c->ctx->default_batch_paths = value;
+    else
+        return fail_arg("ptx_context_set_option: unknown option or bad value");
+    return PTX_OK;
+}
+
+void ptx_context_destroy(ptx_context *c)
+{
+    if (c)
+    {
+        delete c->ctx;
+        delete c;
+    }
+}
+
+int ptx_build_accel(ptx_context *c, const ptx_scene *s)
+{
+    if (!c || !c->ctx || !s)
+        return fail_arg("ptx_build_accel: null argument");
+    PTX_TRY
+    c->ctx->build_accel(s->sc);
+    PTX_CATCH
+}
+
+int ptx_accel_info(const ptx_context *c, int32_t *info5)
+{
+    if (!c || !c->ctx || !info5)
+        return fail_arg("ptx_accel_info: null argument");
+    if (!c->ctx->has_scene())
+    {
+        g_last_error = "state: ptx_build_accel has not been called on this context";
+        return PTX_ERR_STATE;
+    }
+    const ptx::Bvh &b = c->ctx->bvh();
+    info5[0] = static_cast<int32_t>(b.nodes.size());
+    info5[1] = b.n_leaves, info5[2] = b.max_depth, info5[3] = b.max_leaf;
+    info5[4] = c->ctx->brute_force() ? 1 : 0;
+    return PTX_OK;
+}
+
+int ptx_generate_rays(ptx_context *c, double *rays_o, double *rays_d)
+{
+    if (!c || !c->ctx || !rays_o || !rays_d)
+        return fail_arg("ptx_generate_rays: null argument");
+    PTX_TRY
+    c->ctx->generate_rays(rays_o, rays_d);
+    PTX_CATCH
+}
+
+int ptx_first_hit(ptx_context *c, int32_t *face_ids, double *hit_pts)
+{
+    if (!c || !c->ctx || !face_ids)
+        return fail_arg("ptx_first_hit: null argument");
+    PTX_TRY
+    c->ctx->raycast(nullptr, nullptr, 0, face_ids, hit_pts, true, ptx::PTX_MODE_F64_);
+    PTX_CATCH
+}
+
+int ptx_raycast(ptx_context *c, const double *rays_o, const double *rays_d, int64_t n, int32_t *face_ids, double *hit_pts)
+{
+    if (!c || !c->ctx || n < 0 || (n > 0 && (!rays_o || !rays_d || !face_ids)))
+        return fail_arg("ptx_raycast: null argument");
+    PTX_TRY
+    c->ctx->raycast(rays_o, rays_d, n, face_ids, hit_pts, false, ptx::PTX_MODE_F64_);
+    PTX_CATCH
+}
+
+int ptx_vistest(ptx_context *c, const double *p1, const double *p2, int64_t n, int32_t *visible)
+{
+    if (!c || !c->ctx || n < 0 || (n > 0 && (!p1 || !p2 || !visible)))
+        return fail_arg("ptx_vistest: null argument");
+    PTX_TRY
+    c->ctx->vistest(p1, p2, n, visible);
+    PTX_CATCH
+}
+
+int ptx_render(ptx_context *c, const ptx_render_opts *o, double *rgb_sum, int32_t out_is_device, ptx_stats *stats)
+{
+    if (!c || !c->ctx || !rgb_sum)
+        return fail_arg("ptx_render: null argument");
+    PTX_TRY
+    ptx::RenderOpts ro;
+    if (o)
+    {
+        ro.mode = o->mode;
+        ro.spp = o->spp, ro.sample_offset = o->sample_offset, ro.spp_total = o->spp_total;
+        ro.row_begin = o->row_begin, ro.row_end = o->row_end;
+        ro.row_stride = o->row_stride, ro.row_phase = o->row_phase, ro.band = o->band;
+        ro.depth = o->depth;
+        ro.seed = o->seed;
+        ro.batch_paths = o->batch_paths;
+        ro.accumulate = o->accumulate != 0;
+        ro.profile = o->profile != 0;
+    }
+    ptx::RenderStats st;
+    c->ctx->render(ro, rgb_sum, out_is_device != 0, st);
+    if (stats)
+    {
+        stats->paths = st.paths, stats->segments = st.segments, stats->shadow_rays = st.shadow_rays;
+        stats->passes = st.passes;
+        stats->ms_total = st.ms_total;
+        stats->ms_extend = st.ms_class[0], stats->ms_shade = st.ms_class[1], stats->ms_shadow = st.ms_class[2];
+        stats->ms_other = st.ms_class[3];
+    }
+    PTX_CATCH
+}
+
+int ptx_finalize_image(const double *rgb_sum, int64_t n_pixels, double *rgb_out)
+{
+    if (!rgb_sum || !rgb_out || n_pixels < 0)
+        return fail_arg("ptx_finalize_image: null argument");
+    ptx::finalize_image(rgb_sum, n_pixels, rgb_out);
+    return PTX_OK;
+}
+
+int ptx_write_ppm(const char *path, const double *rgb, int32_t width, int32_t height)
+{
+    if (!path || !rgb || width <= 0 || height <= 0)
+        return fail_arg("ptx_write_ppm: bad argument");
+    PTX_TRY
+    ptx::write_ppm(path, rgb, width, height);
+    PTX_CATCH
+}
+
+} // extern "C"

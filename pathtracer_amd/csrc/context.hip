@@ -1,0 +1,619 @@
+// Context: device scene, wavefront state and the render loop (HIP, gfx950).
+//
+// Replaces cPathTracer::Init / Process / RayTracing (src/tracing/cPathTracer.cpp:20-57, 65-86,
+// 517-553 of the reference): instead of an OpenMP loop over rows that runs every path to
+// completion, paths advance one bounce at a time through three kernels (extend, shade, shadow)
+// over dense SoA queues, and a resolve kernel folds each path's (direct, coefficient) stack back
+// to front into the per-pixel sums.
+#include "context.hpp"
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+namespace ptx
+{
+
+#define HIP_CHECK(expr)                                                                                  \
+    do                                                                                                   \
+    {                                                                                                    \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            throw std::runtime_error(std::string("device: ") + #expr + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+namespace
+{
+
+struct DeviceBuffer
+{
+    void *p = nullptr;
+    size_t bytes = 0;
+    void alloc(size_t n)
+    {
+        release();
+        if (n == 0)
+            n = 16;
+        HIP_CHECK(hipMalloc(&p, n));
+        bytes = n;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    ~DeviceBuffer() { release(); }
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+};
+
+template <class T> void upload(DeviceBuffer &b, const std::vector<T> &v, hipStream_t s)
+{
+    b.alloc(v.size() * sizeof(T));
+    if (!v.empty())
+        HIP_CHECK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+}
+
+inline unsigned blocks_for(int64_t n) { return static_cast<unsigned>(std::max<int64_t>(1, (n + BLOCK - 1) / BLOCK)); }
+
+} // namespace
+
+// per-precision device tables + wavefront state
+template <class R> struct Context::Impl
+{
+    DeviceBuffer tri_pre, mats, lights;
+    DeviceBuffer state_mem; // one slab carved into the DState arrays
+    DState<R> st;
+    int64_t capacity = 0;
+    int depth_cap = 0, lights_cap = 0;
+    bool ready = false;
+
+    void build_tables(const Scene &sc, const Bvh &bvh, bool brute, hipStream_t s)
+    {
+        const int F = sc.n_tris();
+        std::vector<R> pre(static_cast<size_t>(std::max(F, 1)) * 12, R(0));
+        for (int k = 0; k < F; k++)
+        {
+            const int f = brute ? k : bvh.tri_order[k];
+            const float *v = &sc.verts[static_cast<size_t>(f) * 9];
+            // columns of the reference's 3x3 system, computed in R exactly as the reference does
+            R p1[3] = {R(v[0]), R(v[1]), R(v[2])}, a[3], b[3];
+            for (int c = 0; c < 3; c++)
+            {
+                a[c] = p1[c] - R(v[3 + c]);
+                b[c] = p1[c] - R(v[6 + c]);
+            }
+            R *o = &pre[static_cast<size_t>(k) * 12];
+            for (int c = 0; c < 3; c++)
+                o[c] = p1[c], o[3 + c] = a[c], o[6 + c] = b[c];
+            R t0 = a[1] * b[2], t1 = b[1] * a[2];
+            o[9] = t0 - t1;
+            t0 = a[2] * b[0], t1 = b[2] * a[0];
+            o[10] = t0 - t1;
+            t0 = a[0] * b[1], t1 = b[0] * a[1];
+            o[11] = t0 - t1;
+        }
+        upload(tri_pre, pre, s);
+
+        std::vector<R> m(static_cast<size_t>(std::max<size_t>(sc.mats.size(), 1)) * MAT_STRIDE, R(0));
+        for (size_t i = 0; i < sc.mats.size(); i++)
+        {
+            const Material &src = sc.mats[i];
+            R *o = &m[i * MAT_STRIDE];
+            for (int c = 0; c < 3; c++)
+                o[c] = R(src.Ka[c]), o[3 + c] = R(src.Kd[c]), o[6 + c] = R(src.Ks[c]);
+            o[9] = R(src.Ni), o[10] = R(src.Ns);
+            o[11] = R(std::pow((1.0 - src.Ni) / (1.0 + src.Ni), 2));           // Schlick R0
+            o[12] = (std::fabs(src.Ni - 1.0) < 1e-5) ? R(0) : R(1);              // BSDF when Ni != 1
+            double ka = std::sqrt(src.Ka[0] * src.Ka[0] + src.Ka[1] * src.Ka[1] + src.Ka[2] * src.Ka[2]);
+            o[13] = ka > 1e-6 ? R(1) : R(0);                                     // emitter
+        }
+        upload(mats, m, s);
+
+        std::vector<R> L(static_cast<size_t>(std::max<size_t>(sc.lights.size(), 1)) * LIGHT_STRIDE, R(0));
+        for (size_t i = 0; i < sc.lights.size(); i++)
+        {
+            const Light &src = sc.lights[i];
+            R *o = &L[i * LIGHT_STRIDE];
+            o[0] = R(src.type);
+            for (int c = 0; c < 3; c++)
+                o[1 + c] = R(src.radiance[c]);
+            if (src.type == 0)
+            {
+                double e10[3], e21[3], n[3];
+                for (int c = 0; c < 3; c++)
+                {
+                    e10[c] = src.p[1][c] - src.p[0][c];
+                    e21[c] = src.p[2][c] - src.p[1][c];
+                }
+                double t0 = e10[1] * e21[2], t1 = e10[2] * e21[1];
+                n[0] = t0 - t1;
+                t0 = e10[2] * e21[0], t1 = e10[0] * e21[2];
+                n[1] = t0 - t1;
+                t0 = e10[0] * e21[1], t1 = e10[1] * e21[0];
+                n[2] = t0 - t1;
+                double z = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+                if (z > 0)
+                {
+                    double nn = std::sqrt(z);
+                    n[0] /= nn, n[1] /= nn, n[2] /= nn;
+                }
+                double l21 = std::sqrt(e21[0] * e21[0] + e21[1] * e21[1] + e21[2] * e21[2]);
+                double l10 = std::sqrt(e10[0] * e10[0] + e10[1] * e10[1] + e10[2] * e10[2]);
+                for (int c = 0; c < 3; c++)
+                    o[4 + c] = R(src.p[0][c]), o[7 + c] = R(e10[c]), o[10 + c] = R(e21[c]), o[13 + c] = R(n[c]);
+                o[16] = R(l21 * l10);
+            }
+            else
+            {
+                for (int c = 0; c < 3; c++)
+                    o[4 + c] = R(src.center[c]);
+                o[7] = R(src.radius);
+            }
+        }
+        upload(lights, L, s);
+        ready = true;
+    }
+
+    // carve the state slab for `n` paths, `depth` bounces and `n_lights` deferred-NEE lights
+    void ensure_state(int64_t n, int depth, int n_lights_deferred)
+    {
+        if (n <= capacity && depth <= depth_cap && n_lights_deferred <= lights_cap)
+            return;
+        n = std::max(n, capacity);
+        depth = std::max(depth, depth_cap);
+        n_lights_deferred = std::max(n_lights_deferred, lights_cap);
+        const size_t N = static_cast<size_t>(n);
+        auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
+        size_t total = 0;
+        auto take = [&](size_t bytes) {
+            size_t off = total;
+            total += align(bytes);
+            return off;
+        };
+        size_t o_ray[2][6], o_pid[2], o_hitprim, o_hitpt[3], o_sd, o_sc, o_ps, o_ni, o_nm, o_nc, o_np, o_cnt, o_stats;
+        for (int q = 0; q < 2; q++)
+        {
+            for (int c = 0; c < 6; c++)
+                o_ray[q][c] = take(N * sizeof(R));
+            o_pid[q] = take(N * 4);
+        }
+        o_hitprim = take(N * 4);
+        for (int c = 0; c < 3; c++)
+            o_hitpt[c] = take(N * sizeof(R));
+        o_sd = take(N * 3 * sizeof(R) * depth);
+        o_sc = take(N * 3 * sizeof(R) * depth);
+        o_ps = take(N * 4);
+        o_ni = take(N * 4);
+        o_nm = take(N * 4);
+        o_nc = take(N * 3 * sizeof(R) * std::max(n_lights_deferred, 0));
+        o_np = take(N * 3 * sizeof(R) * std::max(n_lights_deferred, 0));
+        o_cnt = take(sizeof(uint32_t) * (2 * depth + 2));
+        o_stats = take(sizeof(unsigned long long) * 8);
+        state_mem.alloc(total);
+        char *base = static_cast<char *>(state_mem.p);
+        for (int q = 0; q < 2; q++)
+        {
+            for (int c = 0; c < 3; c++)
+            {
+                st.ray_o[q][c] = reinterpret_cast<R *>(base + o_ray[q][c]);
+                st.ray_d[q][c] = reinterpret_cast<R *>(base + o_ray[q][3 + c]);
+            }
+            st.q_pid[q] = reinterpret_cast<uint32_t *>(base + o_pid[q]);
+        }
+        st.hit_prim = reinterpret_cast<int32_t *>(base + o_hitprim);
+        for (int c = 0; c < 3; c++)
+            st.hit_pt[c] = reinterpret_cast<R *>(base + o_hitpt[c]);
+        st.stack_d = reinterpret_cast<R *>(base + o_sd);
+        st.stack_c = reinterpret_cast<R *>(base + o_sc);
+        st.path_state = reinterpret_cast<uint32_t *>(base + o_ps);
+        st.nee_idx = reinterpret_cast<uint32_t *>(base + o_ni);
+        st.nee_mask = reinterpret_cast<uint32_t *>(base + o_nm);
+        st.nee_c = reinterpret_cast<R *>(base + o_nc);
+        st.nee_p1 = reinterpret_cast<R *>(base + o_np);
+        st.counters = reinterpret_cast<uint32_t *>(base + o_cnt);
+        st.stats = reinterpret_cast<unsigned long long *>(base + o_stats);
+        st.N = n;
+        capacity = n;
+        depth_cap = depth;
+        lights_cap = n_lights_deferred;
+    }
+};
+
+struct Context::Geometry
+{
+    DeviceBuffer tri_face, verts, normals, mat_ids, nodes;
+};
+
+Context::Context(int device) : device_(device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        throw std::runtime_error("device: no HIP device available (the path-tracing core needs a GPU; "
+                                 "there is no CPU fallback)");
+    if (device < 0 || device >= count)
+        throw std::runtime_error("arg: hip_device out of range");
+    HIP_CHECK(hipSetDevice(device));
+    f64_ = new Impl<double>();
+    f32_ = new Impl<float>();
+}
+
+Context::~Context()
+{
+    (void)hipSetDevice(device_);
+    delete f64_;
+    delete f32_;
+    delete geo_;
+}
+
+void Context::set_stream(void *s) { stream_ = s; }
+
+void Context::build_accel(const Scene &sc)
+{
+    HIP_CHECK(hipSetDevice(device_));
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    scene_ = sc; // host copy (camera, tracer settings)
+    brute_ = sc.n_tris() <= brute_force_limit;
+    bvh_ = Bvh();
+    build_bvh(sc.verts.data(), sc.n_tris(), bvh_, 4);
+    if (!brute_ && bvh_.max_depth + 2 > BVH_STACK)
+        throw std::runtime_error("state: BVH deeper than the traversal stack");
+    if (sc.n_square_lights() > 0 && static_cast<int>(sc.lights.size()) > MAX_LIGHTS)
+        throw std::runtime_error("arg: at most 32 lights are supported when square lights are present");
+    if (sc.mats.size() > 65534)
+        throw std::runtime_error("arg: at most 65534 materials are supported");
+    if (sc.depth > 4095)
+        throw std::runtime_error("arg: Depth above 4095 is not supported");
+    delete geo_;
+    geo_ = new Geometry();
+    std::vector<int32_t> face(std::max(sc.n_tris(), 1), 0);
+    for (int k = 0; k < sc.n_tris(); k++)
+        face[k] = brute_ ? k : bvh_.tri_order[k];
+    upload(geo_->tri_face, face, s);
+    upload(geo_->verts, sc.verts, s);
+    upload(geo_->normals, sc.normals, s);
+    upload(geo_->mat_ids, sc.mat_ids, s);
+    upload(geo_->nodes, bvh_.nodes, s);
+    f64_->build_tables(sc, bvh_, brute_, s);
+    f32_->build_tables(sc, bvh_, brute_, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+    have_scene_ = true;
+}
+
+template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::Geometry &g, const void *tri_pre, const void *mats,
+                                                 const void *lights, bool brute)
+{
+    DScene<R> S;
+    S.n_tris = sc.n_tris();
+    S.n_mats = static_cast<int>(sc.mats.size());
+    S.n_lights = static_cast<int>(sc.lights.size());
+    S.n_square = sc.n_square_lights();
+    S.brute = brute;
+    S.enable_indirect = sc.enable_indirect;
+    S.enable_bary = sc.enable_bary_normal && sc.has_normals;
+    S.pad0 = 0;
+    S.tri_pre = static_cast<const R *>(tri_pre);
+    S.tri_face = static_cast<const int32_t *>(g.tri_face.p);
+    S.verts = static_cast<const float *>(g.verts.p);
+    S.normals = static_cast<const float *>(g.normals.p);
+    S.mat_ids = static_cast<const int32_t *>(g.mat_ids.p);
+    S.mats = static_cast<const R *>(mats);
+    S.lights = static_cast<const R *>(lights);
+    S.nodes = static_cast<const BvhNode *>(g.nodes.p);
+    return S;
+}
+
+static DCamera make_camera(const Scene &sc)
+{
+    DCamera c;
+    for (int i = 0; i < 16; i++)
+        c.m[i] = sc.raster2world[i];
+    for (int i = 0; i < 3; i++)
+        c.pos[i] = sc.cam_pos[i];
+    c.width = sc.width, c.height = sc.height;
+    return c;
+}
+
+void Context::require_scene() const
+{
+    if (!have_scene_)
+        throw std::runtime_error("state: ptx_build_accel has not been called on this context");
+}
+
+void Context::generate_rays(double *ro, double *rd)
+{
+    require_scene();
+    HIP_CHECK(hipSetDevice(device_));
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    const int64_t n = static_cast<int64_t>(scene_.width) * scene_.height;
+    DeviceBuffer d_o, d_d;
+    d_o.alloc(n * 24), d_d.alloc(n * 24);
+    hipLaunchKernelGGL(k_camera_rays, dim3(blocks_for(n)), dim3(BLOCK), 0, s, make_camera(scene_), static_cast<double *>(d_o.p),
+                       static_cast<double *>(d_d.p));
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(ro, d_o.p, n * 24, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(rd, d_d.p, n * 24, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void Context::raycast(const double *ro, const double *rd, int64_t n, int32_t *ids, double *pts, bool from_camera, int mode)
+{
+    require_scene();
+    HIP_CHECK(hipSetDevice(device_));
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    if (from_camera)
+        n = static_cast<int64_t>(scene_.width) * scene_.height;
+    if (n <= 0)
+        return;
+    DeviceBuffer d_o, d_d, d_ids, d_pts;
+    if (!from_camera)
+    {
+        d_o.alloc(n * 24), d_d.alloc(n * 24);
+        HIP_CHECK(hipMemcpyAsync(d_o.p, ro, n * 24, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(d_d.p, rd, n * 24, hipMemcpyHostToDevice, s));
+    }
+    d_ids.alloc(n * 4);
+    if (pts)
+        d_pts.alloc(n * 24);
+    DCamera cam = make_camera(scene_);
+    const dim3 grid(blocks_for(n)), block(BLOCK);
+    const double *po = static_cast<const double *>(d_o.p), *pd = static_cast<const double *>(d_d.p);
+    int32_t *pi = static_cast<int32_t *>(d_ids.p);
+    double *pp = pts ? static_cast<double *>(d_pts.p) : nullptr;
+    if (mode == PTX_MODE_F64_)
+    {
+        auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->mats.p, f64_->lights.p, brute_);
+        if (brute_)
+            hipLaunchKernelGGL((k_raycast<double, true>), grid, block, 0, s, S, cam, int(from_camera), po, pd, n, pi, pp);
+        else
+            hipLaunchKernelGGL((k_raycast<double, false>), grid, block, 0, s, S, cam, int(from_camera), po, pd, n, pi, pp);
+    }
+    else
+    {
+        auto S = make_dscene<float>(scene_, *geo_, f32_->tri_pre.p, f32_->mats.p, f32_->lights.p, brute_);
+        if (brute_)
+            hipLaunchKernelGGL((k_raycast<float, true>), grid, block, 0, s, S, cam, int(from_camera), po, pd, n, pi, pp);
+        else
+            hipLaunchKernelGGL((k_raycast<float, false>), grid, block, 0, s, S, cam, int(from_camera), po, pd, n, pi, pp);
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(ids, d_ids.p, n * 4, hipMemcpyDeviceToHost, s));
+    if (pts)
+        HIP_CHECK(hipMemcpyAsync(pts, d_pts.p, n * 24, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void Context::vistest(const double *p1, const double *p2, int64_t n, int32_t *vis)
+{
+    require_scene();
+    HIP_CHECK(hipSetDevice(device_));
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    if (n <= 0)
+        return;
+    DeviceBuffer d1, d2, dv;
+    d1.alloc(n * 24), d2.alloc(n * 24), dv.alloc(n * 4);
+    HIP_CHECK(hipMemcpyAsync(d1.p, p1, n * 24, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(d2.p, p2, n * 24, hipMemcpyHostToDevice, s));
+    auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->mats.p, f64_->lights.p, brute_);
+    const dim3 grid(blocks_for(n)), block(BLOCK);
+    if (brute_)
+        hipLaunchKernelGGL((k_vistest<double, true>), grid, block, 0, s, S, static_cast<const double *>(d1.p),
+                           static_cast<const double *>(d2.p), n, static_cast<int32_t *>(dv.p));
+    else
+        hipLaunchKernelGGL((k_vistest<double, false>), grid, block, 0, s, S, static_cast<const double *>(d1.p),
+                           static_cast<const double *>(d2.p), n, static_cast<int32_t *>(dv.p));
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(vis, dv.p, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// ------------------------------------------------------------------------------------------------
+// render loop
+// ------------------------------------------------------------------------------------------------
+template <class R, bool BRUTE>
+static void run_batch(const DScene<R> &S, const DCamera &cam, const DBatch &B, DState<R> &st, double *sum, hipStream_t s,
+                      RenderTimers *tm)
+{
+    const int depth = B.depth;
+    const dim3 block(BLOCK), grid(blocks_for(B.n_paths));
+    HIP_CHECK(hipMemsetAsync(st.counters, 0, sizeof(uint32_t) * (2 * depth + 2), s));
+    if (tm)
+        tm->mark(s, RenderTimers::OTHER);
+    hipLaunchKernelGGL((k_raygen<R>), grid, block, 0, s, cam, B, st);
+    for (int b = 0; b < depth; b++)
+    {
+        if (tm)
+            tm->mark(s, RenderTimers::EXTEND);
+        hipLaunchKernelGGL((k_extend<R, BRUTE>), grid, block, 0, s, S, st, b);
+        if (tm)
+            tm->mark(s, RenderTimers::SHADE);
+        hipLaunchKernelGGL((k_shade<R>), grid, block, 0, s, S, B, st, b);
+        if (S.n_square > 0)
+        {
+            if (tm)
+                tm->mark(s, RenderTimers::SHADOW);
+            hipLaunchKernelGGL((k_shadow<R, BRUTE>), grid, block, 0, s, S, B, st, b);
+        }
+    }
+    if (tm)
+        tm->mark(s, RenderTimers::OTHER);
+    hipLaunchKernelGGL((k_resolve<R>), dim3(blocks_for(B.n_pix)), block, 0, s, S, B, st, sum, B.image_width);
+    if (tm)
+        tm->mark(s, RenderTimers::END);
+    HIP_CHECK(hipGetLastError());
+}
+
+void RenderTimers::mark(hipStream_t s, int cls)
+{
+    hipEvent_t e;
+    if (used < events.size())
+        e = events[used];
+    else
+    {
+        HIP_CHECK(hipEventCreate(&e));
+        events.push_back(e);
+    }
+    used++;
+    HIP_CHECK(hipEventRecord(e, s));
+    classes.push_back(cls);
+}
+
+void RenderTimers::collect(double ms[4])
+{
+    for (int i = 0; i < 4; i++)
+        ms[i] = 0;
+    for (size_t i = 0; i + 1 < used; i++)
+    {
+        if (classes[i] == END)
+            continue;
+        float t = 0;
+        if (hipEventElapsedTime(&t, events[i], events[i + 1]) == hipSuccess)
+            ms[classes[i]] += t;
+    }
+    used = 0;
+    classes.clear();
+}
+
+RenderTimers::~RenderTimers()
+{
+    for (auto e : events)
+        (void)hipEventDestroy(e);
+}
+
+template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, double *d_sum, RenderStats &stats)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    const Scene &sc = scene_;
+    const int depth = o.depth > 0 ? o.depth : sc.depth;
+    const int spp = o.spp > 0 ? o.spp : sc.spp;
+    const int spp_total = o.spp_total > 0 ? o.spp_total : spp;
+    if (depth > 4095)
+        throw std::runtime_error("arg: depth above 4095 is not supported");
+
+    // rows / columns inside DrawRegion (inclusive ends), clipped to the image
+    int r0 = std::max(sc.region[0], 0), r1 = std::min(sc.region[2], sc.height - 1) + 1;
+    int c0 = std::max(sc.region[1], 0), c1 = std::min(sc.region[3], sc.width - 1) + 1;
+    if (o.row_end > o.row_begin)
+    {
+        r0 = std::max(r0, o.row_begin);
+        r1 = std::min(r1, o.row_end);
+    }
+    if (r1 <= r0 || c1 <= c0)
+        return;
+    // interleaved bands: local row lr <-> image row
+    const int stride = std::max(o.row_stride, 1), band = std::max(o.band, 1), phase = o.row_phase;
+    int n_local_rows;
+    if (stride <= 1)
+        n_local_rows = r1 - r0;
+    else
+    {
+        n_local_rows = 0;
+        for (int r = 0; r < r1 - r0; r++)
+            n_local_rows += ((r / band) % stride) == phase;
+    }
+    if (n_local_rows <= 0)
+        return;
+    const int n_cols = c1 - c0;
+
+    int64_t batch = o.batch_paths > 0 ? o.batch_paths : default_batch_paths;
+    batch = std::max<int64_t>(batch, n_cols);
+    const int rows_per_chunk = static_cast<int>(std::min<int64_t>(n_local_rows, std::max<int64_t>(1, batch / n_cols)));
+    const int64_t pix_per_chunk = static_cast<int64_t>(rows_per_chunk) * n_cols;
+    const int samples_per_batch = static_cast<int>(std::min<int64_t>(spp, std::max<int64_t>(1, batch / pix_per_chunk)));
+    const int64_t cap = pix_per_chunk * samples_per_batch;
+    if (cap >= (int64_t(1) << 31))
+        throw std::runtime_error("arg: batch_paths must stay below 2^31");
+    const int deferred = sc.n_square_lights() > 0 ? static_cast<int>(sc.lights.size()) : 0;
+    im.ensure_state(cap, depth, deferred);
+    HIP_CHECK(hipMemsetAsync(im.st.stats, 0, sizeof(unsigned long long) * 8, s));
+
+    auto S = make_dscene<R>(sc, *geo_, im.tri_pre.p, im.mats.p, im.lights.p, brute_);
+    DCamera cam = make_camera(sc);
+    RenderTimers *tm = o.profile ? &timers_ : nullptr;
+
+    hipEvent_t ev0, ev1;
+    HIP_CHECK(hipEventCreate(&ev0));
+    HIP_CHECK(hipEventCreate(&ev1));
+    HIP_CHECK(hipEventRecord(ev0, s));
+    uint64_t passes = 0;
+    for (int lr0 = 0; lr0 < n_local_rows; lr0 += rows_per_chunk)
+    {
+        const int nr = std::min(rows_per_chunk, n_local_rows - lr0);
+        for (int s0 = 0; s0 < spp; s0 += samples_per_batch)
+        {
+            DBatch B;
+            B.row0 = lr0, B.n_rows = nr;
+            B.col0 = c0, B.n_cols = n_cols;
+            B.band = band, B.row_stride = stride, B.row_phase = phase, B.region_row0 = r0;
+            B.image_width = sc.width;
+            B.n_samples = std::min(samples_per_batch, spp - s0);
+            B.sample0 = o.sample_offset + s0;
+            B.spp_total = spp_total, B.depth = depth;
+            B.seed = o.seed;
+            B.n_pix = static_cast<int64_t>(nr) * n_cols;
+            B.n_paths = B.n_pix * B.n_samples;
+            if (brute_)
+                run_batch<R, true>(S, cam, B, im.st, d_sum, s, tm);
+            else
+                run_batch<R, false>(S, cam, B, im.st, d_sum, s, tm);
+            passes++;
+        }
+    }
+    HIP_CHECK(hipEventRecord(ev1, s));
+    unsigned long long h_stats[8] = {0};
+    HIP_CHECK(hipMemcpyAsync(h_stats, im.st.stats, sizeof(h_stats), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    stats.segments = h_stats[0];
+    stats.shadow_rays = h_stats[1];
+    stats.paths = h_stats[2];
+    stats.passes = passes;
+    stats.ms_total = ms;
+    if (tm)
+        tm->collect(stats.ms_class);
+}
+
+void Context::render(const RenderOpts &o, double *sum, bool out_is_device, RenderStats &stats)
+{
+    require_scene();
+    HIP_CHECK(hipSetDevice(device_));
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    stats = RenderStats();
+    const int64_t n = static_cast<int64_t>(scene_.width) * scene_.height;
+    DeviceBuffer tmp;
+    double *d_sum = sum;
+    if (!out_is_device)
+    {
+        tmp.alloc(n * 24);
+        d_sum = static_cast<double *>(tmp.p);
+        if (o.accumulate)
+            HIP_CHECK(hipMemcpyAsync(d_sum, sum, n * 24, hipMemcpyHostToDevice, s));
+    }
+    if (!o.accumulate)
+        HIP_CHECK(hipMemsetAsync(d_sum, 0, n * 24, s));
+    if (scene_.enable_path_tracing)
+    {
+        if (o.mode == PTX_MODE_F64_)
+            render_impl(*f64_, o, d_sum, stats);
+        else if (o.mode == PTX_MODE_F32_)
+            render_impl(*f32_, o, d_sum, stats);
+        else
+            throw std::runtime_error("arg: unknown render mode");
+    }
+    if (!out_is_device)
+    {
+        HIP_CHECK(hipMemcpyAsync(sum, d_sum, n * 24, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+}
+
+} // namespace ptx

@@ -1,0 +1,97 @@
+// One rendering context per GPU: device copies of the scene and the wavefront state.
+#pragma once
+#include "bvh.hpp"
+#include "scene.hpp"
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <vector>
+
+namespace ptx
+{
+
+constexpr int PTX_MODE_F64_ = 0;
+constexpr int PTX_MODE_F32_ = 1;
+
+struct RenderOpts
+{
+    int mode = PTX_MODE_F64_;
+    int spp = 0, sample_offset = 0, spp_total = 0;
+    int row_begin = 0, row_end = 0;
+    int row_stride = 1, row_phase = 0, band = 1;
+    int depth = 0;
+    uint64_t seed = 13;
+    int64_t batch_paths = 0;
+    bool accumulate = false;
+    bool profile = false;
+};
+
+struct RenderStats
+{
+    uint64_t paths = 0, segments = 0, shadow_rays = 0, passes = 0;
+    double ms_total = 0;
+    double ms_class[4] = {0, 0, 0, 0}; // extend, shade, shadow, other
+};
+
+// per-kernel-class timing with HIP events on the render stream (profiling mode only)
+struct RenderTimers
+{
+    enum
+    {
+        EXTEND = 0,
+        SHADE = 1,
+        SHADOW = 2,
+        OTHER = 3,
+        END = 4
+    };
+    std::vector<hipEvent_t> events;
+    std::vector<int> classes;
+    size_t used = 0;
+    void mark(hipStream_t s, int cls);
+    void collect(double ms[4]);
+    ~RenderTimers();
+};
+
+class Context
+{
+public:
+    explicit Context(int device);
+    ~Context();
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+
+    void set_stream(void *hip_stream);
+    void build_accel(const Scene &sc);
+    void generate_rays(double *rays_o, double *rays_d);
+    void raycast(const double *ro, const double *rd, int64_t n, int32_t *ids, double *pts, bool from_camera, int mode);
+    void vistest(const double *p1, const double *p2, int64_t n, int32_t *vis);
+    void render(const RenderOpts &o, double *sum, bool out_is_device, RenderStats &stats);
+
+    const Bvh &bvh() const { return bvh_; }
+    bool brute_force() const { return brute_; }
+    const Scene &scene() const { return scene_; }
+    bool has_scene() const { return have_scene_; }
+
+    // scenes up to this many triangles are intersected by the all-triangles loop
+    int brute_force_limit = 64;
+    int64_t default_batch_paths = int64_t(1) << 22;
+
+    struct Geometry;
+    template <class R> struct Impl;
+
+private:
+    void require_scene() const;
+    template <class R> void render_impl(Impl<R> &im, const RenderOpts &o, double *d_sum, RenderStats &stats);
+
+    int device_;
+    void *stream_ = nullptr;
+    Scene scene_;
+    Bvh bvh_;
+    bool brute_ = true, have_scene_ = false;
+    Geometry *geo_ = nullptr;
+    Impl<double> *f64_ = nullptr;
+    Impl<float> *f32_ = nullptr;
+    RenderTimers timers_;
+};
+
+} // namespace ptx

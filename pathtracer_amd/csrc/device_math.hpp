@@ -1,0 +1,329 @@
+// Device-side arithmetic of the path tracer (HIP, gfx950).
+//
+// Everything is templated on the scalar type R: R = double reproduces the reference's arithmetic
+// operation by operation (this translation unit is compiled with -ffp-contract=off, so no product
+// is fused into a following sum); R = float is the fast path.
+//
+// Reference formulas restated here (paths relative to the reference root):
+//   ray/triangle ........ src/util/cMathUtil.cpp:141-163,205-227 (3x3 cofactor inverse)
+//   reflect / refract ... src/util/cGeoUtil.cpp:117-127, 131-172
+//   barycentric weights . src/util/cGeoUtil.cpp:174-231
+//   hemisphere sample ... src/util/cMathUtil.cpp:230-267, 40-55, 340-345
+//   lights .............. src/tracing/cLight.cpp:73-109, 188-255
+//   BxDFs ............... src/tracing/cBxDF.cpp:69-95, 156-227
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptx
+{
+
+template <class R> struct V3
+{
+    R x, y, z;
+};
+
+template <class R> __device__ __forceinline__ V3<R> mk(R x, R y, R z) { return V3<R>{x, y, z}; }
+template <class R> __device__ __forceinline__ V3<R> operator+(V3<R> a, V3<R> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class R> __device__ __forceinline__ V3<R> operator-(V3<R> a, V3<R> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class R> __device__ __forceinline__ V3<R> operator-(V3<R> a) { return {-a.x, -a.y, -a.z}; }
+template <class R> __device__ __forceinline__ V3<R> operator*(V3<R> a, R s) { return {a.x * s, a.y * s, a.z * s}; }
+template <class R> __device__ __forceinline__ V3<R> operator*(R s, V3<R> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <class R> __device__ __forceinline__ V3<R> operator/(V3<R> a, R s) { return {a.x / s, a.y / s, a.z / s}; }
+template <class R> __device__ __forceinline__ R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class R> __device__ __forceinline__ V3<R> cross(V3<R> a, V3<R> b)
+{
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <class R> __device__ __forceinline__ R norm(V3<R> a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+// Eigen's normalized(): divide by the norm when the squared norm is > 0, else leave unchanged
+template <class R> __device__ __forceinline__ V3<R> normalized(V3<R> a)
+{
+    R z = a.x * a.x + a.y * a.y + a.z * a.z;
+    if (z > R(0))
+    {
+        R n = sqrt(z);
+        return {a.x / n, a.y / n, a.z / n};
+    }
+    return a;
+}
+template <class R> __device__ __forceinline__ bool has_nan(V3<R> a) { return isnan(a.x) || isnan(a.y) || isnan(a.z); }
+
+template <class R> struct Consts;
+template <> struct Consts<double>
+{
+    static constexpr double pi = 3.14159265358979323846;
+    static constexpr double tri_eps = 1e-10;  // barycentric / t slack of the reference test
+    static constexpr double self_eps = 1e-6;  // hits closer than this are ignored
+    static constexpr double big = 1.7976931348623157e308;
+};
+template <> struct Consts<float>
+{
+    static constexpr float pi = 3.14159265358979323846f;
+    static constexpr float tri_eps = 1e-6f;
+    static constexpr float self_eps = 1e-4f;
+    static constexpr float big = 3.4028234e38f;
+};
+
+// ---------------------------------------------------------------------------------------------
+// counter-based RNG: a draw is a pure function of (seed, pixel, sample, bounce, dimension)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ uint64_t rng_pixel_key(uint64_t seed, uint32_t pixel)
+{
+    return mix64(seed + 0x9E3779B97F4A7C15ULL * (uint64_t(pixel) + 1));
+}
+template <class R> __device__ __forceinline__ R rng_draw(uint64_t pixel_key, uint32_t sample, uint32_t bounce, uint32_t dim);
+template <> __device__ __forceinline__ double rng_draw<double>(uint64_t k, uint32_t s, uint32_t b, uint32_t d)
+{
+    uint64_t h = mix64(k ^ ((uint64_t(s) << 32) | (uint64_t(b) << 8) | uint64_t(d)));
+    return double(h >> 11) * (1.0 / 9007199254740992.0);
+}
+template <> __device__ __forceinline__ float rng_draw<float>(uint64_t k, uint32_t s, uint32_t b, uint32_t d)
+{
+    uint64_t h = mix64(k ^ ((uint64_t(s) << 32) | (uint64_t(b) << 8) | uint64_t(d)));
+    return float(h >> 40) * (1.0f / 16777216.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ray / triangle.  T points at the 12 precomputed scalars of one triangle:
+//   p1, a = p1 - p2, b = p1 - p3, n = (a.y b.z - b.y a.z, a.z b.x - b.z a.x, a.x b.y - b.x a.y)
+// (columns 0 and 1 of the reference's 3x3 system and the three cofactors that do not involve the
+// ray).  Returns true when the reference accepts the hit and writes t.
+// ---------------------------------------------------------------------------------------------
+template <class R> __device__ __forceinline__ bool tri_test(const R *__restrict__ T, V3<R> o, V3<R> d, R &t_out)
+{
+    const R eps = Consts<R>::tri_eps;
+    const R ax = T[3], ay = T[4], az = T[5];
+    const R bx = T[6], by = T[7], bz = T[8];
+    const R rx = T[0] - o.x, ry = T[1] - o.y, rz = T[2] - o.z;
+    const R c00 = by * d.z - d.y * bz;
+    const R c10 = bz * d.x - d.z * bx;
+    const R c20 = bx * d.y - d.x * by;
+    const R det = c00 * ax + c10 * ay + c20 * az;
+    const R inv = R(1) / det;
+    const R beta = (c00 * inv) * rx + (c10 * inv) * ry + (c20 * inv) * rz;
+    const R i10 = (d.y * az - ay * d.z) * inv;
+    const R i11 = (d.z * ax - az * d.x) * inv;
+    const R i12 = (d.x * ay - ax * d.y) * inv;
+    const R gamma = i10 * rx + i11 * ry + i12 * rz;
+    const R t = (T[9] * inv) * rx + (T[10] * inv) * ry + (T[11] * inv) * rz;
+    const R alpha = R(1) - beta - gamma;
+    t_out = t;
+    return (R(0) - eps < alpha) && (alpha < R(1) + eps) && (R(0) - eps < beta) && (beta < R(1) + eps) &&
+           (R(0) - eps < gamma) && (gamma < R(1) + eps) && (t > R(0) - eps);
+}
+
+// ---------------------------------------------------------------------------------------------
+// geometry helpers
+// ---------------------------------------------------------------------------------------------
+template <class R> __device__ __forceinline__ V3<R> reflect(V3<R> n, V3<R> in)
+{
+    R k = R(2) * dot(n, -in);
+    return k * n + in;
+}
+
+// NaN components on total internal reflection
+template <class R> __device__ __forceinline__ V3<R> refract(V3<R> n, V3<R> in, R ni)
+{
+    if (dot(n, in) > R(0))
+    {
+        n = -n;
+        ni = R(1) / ni;
+    }
+    V3<R> nxi = cross(n, in);
+    V3<R> c = cross(n, -nxi);
+    R s = sqrt(R(1) - ni * ni * dot(nxi, nxi));
+    return ni * c - n * s;
+}
+
+// 3x3 inverse times vector, cofactors of column 0 / determinant along column 0 (row-major m)
+template <class R> __device__ __forceinline__ V3<R> solve3(const R *m, V3<R> p)
+{
+    R c00 = m[4] * m[8] - m[5] * m[7];
+    R c10 = m[7] * m[2] - m[8] * m[1];
+    R c20 = m[1] * m[5] - m[2] * m[4];
+    R det = c00 * m[0] + c10 * m[3] + c20 * m[6];
+    R id = R(1) / det;
+    R i0 = c00 * id, i1 = c10 * id, i2 = c20 * id;
+    R i3 = (m[5] * m[6] - m[3] * m[8]) * id;
+    R i4 = (m[8] * m[0] - m[6] * m[2]) * id;
+    R i5 = (m[2] * m[3] - m[0] * m[5]) * id;
+    R i6 = (m[3] * m[7] - m[4] * m[6]) * id;
+    R i7 = (m[6] * m[1] - m[7] * m[0]) * id;
+    R i8 = (m[0] * m[4] - m[1] * m[3]) * id;
+    return {i0 * p.x + i1 * p.y + i2 * p.z, i3 * p.x + i4 * p.y + i5 * p.z, i6 * p.x + i7 * p.y + i8 * p.z};
+}
+
+// barycentric weights of p w.r.t. (a,b,c): [a b c]^-1 p with all-zero rows regularised, normalised
+template <class R> __device__ __forceinline__ V3<R> barycentric(V3<R> p, V3<R> a, V3<R> b, V3<R> c)
+{
+    R m[9] = {a.x, b.x, c.x, a.y, b.y, c.y, a.z, b.z, c.z};
+    R pv[3] = {p.x, p.y, p.z};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+    {
+        R rn = sqrt(m[i * 3] * m[i * 3] + m[i * 3 + 1] * m[i * 3 + 1] + m[i * 3 + 2] * m[i * 3 + 2]);
+        if (rn < R(1e-10))
+        {
+            m[i * 3] += R(1e-6), m[i * 3 + 1] += R(1e-6), m[i * 3 + 2] += R(1e-6);
+            pv[i] += R(1e-6);
+        }
+    }
+    return normalized(solve3(m, V3<R>{pv[0], pv[1], pv[2]}));
+}
+
+// direction about `n`: elevation theta = acos(1 - xi1), azimuth 2 pi xi2, rotated from +Y to n by
+// the quaternion of axis normalize(Y x (n - Y)) and angle acos(n.y)
+template <class R> __device__ __forceinline__ V3<R> sample_hemisphere(V3<R> n, R xi1, R xi2)
+{
+    const R pi = Consts<R>::pi;
+    R theta = acos(R(1) - xi1), phi = R(2) * pi * xi2;
+    R ct = cos(theta), st = sin(theta);
+    V3<R> res = {ct * cos(phi), st, -ct * sin(phi)};
+    // Y x (n - Y) = (n.z, 0, -n.x) exactly
+    V3<R> axis = {n.z, R(0), -n.x};
+    R z2 = axis.x * axis.x + axis.y * axis.y + axis.z * axis.z;
+    R angle = acos(n.y);
+    if (z2 > R(0))
+    {
+        R nn = sqrt(z2);
+        axis = {axis.x / nn, axis.y / nn, axis.z / nn};
+    }
+    else
+    {
+        axis = {R(1), R(0), R(0)};
+        if (fabs(n.y - R(1)) < R(1e-10))
+            angle = R(0);
+        else if (fabs(n.y + R(1)) < R(1e-10))
+            angle = pi;
+    }
+    V3<R> av = axis * angle;
+    R th = norm(av);
+    if (th < R(1e-7))
+        return res;
+    R h = th / R(2);
+    R qw = cos(h), s = sin(h);
+    V3<R> u = normalized(av);
+    V3<R> qv = {u.x * s, u.y * s, u.z * s};
+    V3<R> uv = cross(qv, res);
+    uv = uv + uv;
+    return res + qw * uv + cross(qv, uv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tables in device memory
+// ---------------------------------------------------------------------------------------------
+// material: 16 scalars  Ka[3] Kd[3] Ks[3] Ni Ns R0 is_bsdf is_emissive pad pad
+constexpr int MAT_STRIDE = 16;
+// light: 24 scalars  type Li[3] | square: P0[3] e10[3] e21[3] N[3] area | sphere: C[3] radius
+constexpr int LIGHT_STRIDE = 24;
+
+template <class R> __device__ __forceinline__ V3<R> brdf_eval(const R *__restrict__ m, V3<R> wi, V3<R> wo, V3<R> n)
+{
+    const R pi = Consts<R>::pi;
+    R ca = dot(reflect(n, wi), wo);
+    R ns = m[10];
+    R pw = (ns == R(1)) ? ca : pow(ca, ns);
+    R k = (ns + R(2));
+    return {m[3] / pi + m[6] * k / (R(2) * pi) * pw, m[4] / pi + m[7] * k / (R(2) * pi) * pw,
+            m[5] / pi + m[8] * k / (R(2) * pi) * pw};
+}
+
+template <class R> __device__ __forceinline__ V3<R> bsdf_eval(const R *__restrict__ m, V3<R> wi, V3<R> wo, V3<R> n)
+{
+    V3<R> ideal = refract(n, wi, R(1) / m[9]);
+    if (has_nan(ideal))
+        ideal = reflect(n, wi);
+    R c = dot(ideal, wo);
+    if (c < R(0))
+        c = R(0);
+    R v = R(1) / (R(4) * Consts<R>::pi) * c;
+    return {v, v, v};
+}
+
+template <class R> __device__ __forceinline__ V3<R> bxdf_eval(const R *__restrict__ m, V3<R> wi, V3<R> wo, V3<R> n)
+{
+    return (m[12] != R(0)) ? bsdf_eval(m, wi, wo, n) : brdf_eval(m, wi, wo, n);
+}
+
+// next direction + indirect coefficient.  xi1, xi2: the two draws of this bounce (glass uses xi1)
+template <class R>
+__device__ __forceinline__ void bxdf_sample(const R *__restrict__ m, V3<R> n, V3<R> wo, R xi1, R xi2, V3<R> &wi, V3<R> &coef)
+{
+    const R pi = Consts<R>::pi;
+    if (m[12] == R(0))
+    {
+        R pdf = R(1) / (R(2) * pi);
+        wi = sample_hemisphere(n, xi1, xi2);
+        V3<R> f = brdf_eval(m, -wi, wo, n);
+        R c = dot(n, wi);
+        coef = {f.x * c / pdf, f.y * c / pdf, f.z * c / pdf};
+    }
+    else
+    {
+        R R0 = m[11];
+        V3<R> mwo = -wo;
+        R Rf = R0 + (R(1) - R0) * pow(R(1) - fabs(dot(n, mwo)), R(5));
+        if (xi1 < Rf)
+            wi = reflect(n, mwo);
+        else
+        {
+            wi = refract(n, mwo, R(1) / R(1.5));
+            if (has_nan(wi))
+                wi = reflect(n, mwo);
+        }
+        R pdf = R(1) / (R(4) * pi);
+        R v = (R(1) * pdf * R(1)) / pdf;
+        coef = {v, v, v};
+    }
+}
+
+// square light: uniform point on the parallelogram, one-sided; returns pdf (0 = skip)
+template <class R>
+__device__ __forceinline__ R square_light_sample(const R *__restrict__ L, V3<R> ref, R xi1, R xi2, V3<R> &ro, V3<R> &rd)
+{
+    V3<R> P0 = {L[4], L[5], L[6]}, e10 = {L[7], L[8], L[9]}, e21 = {L[10], L[11], L[12]}, N = {L[13], L[14], L[15]};
+    R area = L[16];
+    V3<R> s = P0 + e10 * xi1;
+    s = s + e21 * xi2;
+    V3<R> dir = normalized(ref - s);
+    R c = dot(dir, N);
+    if (c <= R(0))
+        return R(0);
+    ro = s;
+    rd = dir;
+    R r = norm(s - ref);
+    return r * r / (area * c) * (R(1) / (R(2) * Consts<R>::pi));
+}
+
+// sphere light: the returned ray starts at the shaded point itself (so it is never shadowed) and
+// points from the centre towards the point; only the cone pdf survives.  Inside the sphere a
+// uniform surface point is used (3 draws).
+template <class R>
+__device__ __forceinline__ R sphere_light_sample(const R *__restrict__ L, V3<R> ref, R xi1, R xi2, R xi3, V3<R> &ro, V3<R> &rd)
+{
+    const R pi = Consts<R>::pi;
+    V3<R> C = {L[4], L[5], L[6]};
+    R rad = L[7];
+    R dc = norm(ref - C);
+    ro = ref;
+    if (dc > rad)
+    {
+        R max_theta = asin(rad / dc);
+        V3<R> to_light = normalized(C - ref);
+        rd = -to_light;
+        return R(1) / (R(2) * pi * (R(1) - cos(max_theta)));
+    }
+    V3<R> u = normalized(V3<R>{xi1 - R(0.5), xi2 - R(0.5), xi3 - R(0.5)});
+    V3<R> lp = u * rad + C;
+    rd = normalized(ref - lp);
+    return R(1) / (R(4) * pi);
+}
+
+} // namespace ptx

@@ -1,0 +1,638 @@
+// Wavefront path-tracing kernels for gfx950 (wave64).  Templated on the scalar type R and on the
+// intersector (BRUTE: every triangle, in face order, from a wave-uniform table the compiler reads
+// through the scalar cache; otherwise the flattened BVH with a per-lane LDS stack).
+//
+// Kernel <-> reference map (paths relative to the reference root):
+//   k_raygen / k_first_hit ... cPathTracer::GenerateRay        src/tracing/cPathTracer.cpp:129-213
+//   closest_hit .............. cAccelStruct::RayCast           src/geometry/cAccelStruct.cpp:28-54
+//   visible .................. cAccelStruct::VisTest           src/geometry/cAccelStruct.cpp:56-87
+//   k_extend ................. the RayCast call of the bounce loop, cPathTracer.cpp:596
+//   k_shade .................. bounce body: miss/emitter termination, shading normal, NEE set-up
+//                              (cBxDF::Sample_Li, src/tracing/cBxDF.cpp:16-52), next direction
+//                              (Sample_f), cPathTracer.cpp:598-673; appends the survivors to the
+//                              next queue (wave64 ballot + prefix sum, one atomic per workgroup)
+//   k_shadow ................. the VisTest calls of Sample_Li and the in-order sum of the per-light
+//                              terms
+//   k_resolve ................ back-to-front combine with the per-bounce max-clamp and the
+//                              per-pixel average, cPathTracer.cpp:679-692
+#pragma once
+#include "bvh.hpp"
+#include "device_math.hpp"
+
+namespace ptx
+{
+
+constexpr int BLOCK = 256;      // threads per workgroup (4 waves)
+constexpr int BVH_STACK = 48;   // per-lane traversal stack entries (LDS)
+constexpr int MAX_LIGHTS = 32;  // lights per scene when NEE terms are deferred to k_shadow (mask bits)
+
+template <class R> struct DScene
+{
+    int n_tris, n_mats, n_lights, n_square;
+    int brute, enable_indirect, enable_bary, pad0;
+    const R *tri_pre;          // [n_tris][12] in intersector order: p1, p1-p2, p1-p3, cofactors
+    const int32_t *tri_face;   // intersector order -> face id
+    const float *verts;        // [n_faces][9]  by face id
+    const float *normals;      // [n_faces][9]
+    const int32_t *mat_ids;    // [n_faces]
+    const R *mats;             // [n_mats][MAT_STRIDE]
+    const R *lights;           // [n_lights][LIGHT_STRIDE]
+    const BvhNode *nodes;
+};
+
+struct DCamera
+{
+    double m[16];    // raster -> world
+    double pos[3];
+    int width, height;
+};
+
+// region of the image one batch covers, and its mapping to path slots
+struct DBatch
+{
+    int row0, n_rows;        // local rows of this batch: [row0, row0 + n_rows)
+    int col0, n_cols;        // columns [col0, col0 + n_cols)
+    int band, row_stride, row_phase, region_row0; // local row -> image row (interleaved bands)
+    int image_width;         // W of the full image (pixel index of the RNG key = row * W + col)
+    int n_samples;           // samples of this batch
+    int sample0;             // global index of its first sample
+    int spp_total, depth;
+    uint64_t seed;
+    int64_t n_pix;           // n_rows * n_cols
+    int64_t n_paths;         // n_pix * n_samples
+};
+
+__device__ __forceinline__ int local_row_to_image_row(const DBatch &b, int lr)
+{
+    if (b.row_stride <= 1)
+        return b.region_row0 + lr;
+    int bi = lr / b.band, off = lr % b.band;
+    return b.region_row0 + (bi * b.row_stride + b.row_phase) * b.band + off;
+}
+
+// per-batch device state, SoA.  Arrays indexed by `i` are queue slots (dense, re-packed every
+// bounce); arrays indexed by `pid` are path slots (pid = sample_local * n_pix + pixel_local).
+template <class R> struct DState
+{
+    R *ray_o[2][3], *ray_d[2][3]; // [2 queues][component][N]
+    uint32_t *q_pid[2];           // [N]
+    int32_t *hit_prim;            // [N] ordered triangle index or -1
+    R *hit_pt[3];                 // [N]
+    R *stack_d;                   // [depth][3][N] by pid
+    R *stack_c;                   // [depth][3][N] by pid
+    uint32_t *path_state;         // [N] by pid: (len << 16) | (tail material + 1)
+    // deferred NEE (only when the scene has square lights).  The per-light terms stay at the
+    // queue slot i of the path; only the list of slots that need visibility tests is compacted.
+    uint32_t *nee_idx;            // [N] dense list of queue slots with pending tests
+    uint32_t *nee_mask;           // [N] by queue slot: bit l = light l needs a visibility test
+    R *nee_c;                     // [n_lights][3][N] by queue slot: per-light contribution
+    R *nee_p1;                    // [n_lights][3][N] by queue slot: light sample point
+    uint32_t *counters;           // [0..depth]: queue sizes per bounce; [depth+1 .. 2 depth+1): nee sizes
+    unsigned long long *stats;    // [0] segments [1] shadow rays [2] paths
+    int64_t N;                    // capacity (paths per batch)
+};
+
+// ---------------------------------------------------------------------------------------------
+// intersectors
+// ---------------------------------------------------------------------------------------------
+template <class R> __device__ __forceinline__ R box_entry(const float *lo, const float *hi, V3<R> o, V3<R> inv, R t0, R t1)
+{
+    // slab test; returns entry distance or a negative "miss" marker (-2)
+    R ax = (R(lo[0]) - o.x) * inv.x, bx = (R(hi[0]) - o.x) * inv.x;
+    R ay = (R(lo[1]) - o.y) * inv.y, by = (R(hi[1]) - o.y) * inv.y;
+    R az = (R(lo[2]) - o.z) * inv.z, bz = (R(hi[2]) - o.z) * inv.z;
+    R tmin = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), t0));
+    R tmax = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), t1));
+    // widen by a few ulps so rounding can never cull a box the exact test would need
+    const R k = sizeof(R) == 8 ? R(1e-12) : R(1e-5);
+    return (tmin - fabs(tmin) * k - k <= tmax + fabs(tmax) * k + k) ? tmin : R(-2);
+}
+
+// closest hit.  Returns the intersector-order triangle index (or -1) and the hit point.
+// Winner = smallest |p - o| among accepted hits with |p - o| > self_eps; ties -> lowest face id.
+template <class R, bool BRUTE>
+__device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d, V3<R> &pt, int *stk)
+{
+    R best = Consts<R>::big;
+    int target = -1;
+    const R self_eps = Consts<R>::self_eps;
+    if (BRUTE)
+    {
+        const R *__restrict__ T = S.tri_pre;
+        for (int f = 0; f < S.n_tris; f++)
+        {
+            R t;
+            if (tri_test(T + f * 12, o, d, t))
+            {
+                V3<R> p = o + t * d;
+                R dist = norm(p - o);
+                if (dist < best && dist > self_eps)
+                {
+                    best = dist;
+                    target = f;
+                    pt = p;
+                }
+            }
+        }
+        return target;
+    }
+    int best_face = 0x7fffffff;
+    V3<R> inv = {R(1) / d.x, R(1) / d.y, R(1) / d.z};
+    int sp = 0;
+    int node = 0;
+    const int lane_stride = BLOCK;
+    for (;;)
+    {
+        const BvhNode nd = S.nodes[node];
+        R tmax = best * (R(1) + (sizeof(R) == 8 ? R(1e-9) : R(1e-4))) + R(1e-9);
+        R e0 = box_entry(nd.lo0, nd.hi0, o, inv, R(-1e-6), tmax);
+        R e1 = box_entry(nd.lo1, nd.hi1, o, inv, R(-1e-6), tmax);
+        int c0 = nd.c0, c1 = nd.c1;
+        bool h0 = e0 > R(-1.5), h1 = e1 > R(-1.5);
+        // leaves are tested right away; internal children are visited near-first
+#pragma unroll
+        for (int side = 0; side < 2; side++)
+        {
+            int c = side == 0 ? c0 : c1;
+            bool h = side == 0 ? h0 : h1;
+            if (h && c < 0)
+            {
+                int enc = ~c, first = enc >> 3, cnt = (enc & 7) + 1;
+                for (int k = first; k < first + cnt; k++)
+                {
+                    R t;
+                    if (tri_test(S.tri_pre + (size_t)k * 12, o, d, t))
+                    {
+                        V3<R> p = o + t * d;
+                        R dist = norm(p - o);
+                        int face = S.tri_face[k];
+                        if (dist > self_eps && (dist < best || (dist == best && face < best_face)))
+                        {
+                            best = dist;
+                            best_face = face;
+                            target = k;
+                            pt = p;
+                        }
+                    }
+                }
+            }
+        }
+        bool i0 = h0 && c0 >= 0, i1 = h1 && c1 >= 0;
+        if (i0 && i1)
+        {
+            int near = e0 <= e1 ? c0 : c1, far = e0 <= e1 ? c1 : c0;
+            if (sp < BVH_STACK)
+                stk[sp * lane_stride] = far;
+            sp++;
+            node = near;
+        }
+        else if (i0)
+            node = c0;
+        else if (i1)
+            node = c1;
+        else
+        {
+            if (sp == 0)
+                break;
+            sp--;
+            node = stk[sp * lane_stride];
+        }
+    }
+    return target;
+}
+
+// segment visibility p1 -> p2: blocked iff some triangle has self_eps < t < |p1 - p2| - self_eps
+template <class R, bool BRUTE> __device__ __forceinline__ bool visible(const DScene<R> &S, V3<R> p1, V3<R> p2, int *stk)
+{
+    const R self_eps = Consts<R>::self_eps;
+    R dist = norm(p1 - p2);
+    V3<R> dir = normalized(p2 - p1);
+    if (BRUTE)
+    {
+        const R *__restrict__ T = S.tri_pre;
+        bool blocked = false;
+        for (int f = 0; f < S.n_tris; f++)
+        {
+            R t;
+            if (tri_test(T + f * 12, p1, dir, t) && t < dist - self_eps && t > self_eps)
+                blocked = true;
+        }
+        return !blocked;
+    }
+    V3<R> inv = {R(1) / dir.x, R(1) / dir.y, R(1) / dir.z};
+    int sp = 0, node = 0;
+    const int lane_stride = BLOCK;
+    for (;;)
+    {
+        const BvhNode nd = S.nodes[node];
+        R e0 = box_entry(nd.lo0, nd.hi0, p1, inv, R(-1e-6), dist);
+        R e1 = box_entry(nd.lo1, nd.hi1, p1, inv, R(-1e-6), dist);
+        int c0 = nd.c0, c1 = nd.c1;
+        bool h0 = e0 > R(-1.5), h1 = e1 > R(-1.5);
+#pragma unroll
+        for (int side = 0; side < 2; side++)
+        {
+            int c = side == 0 ? c0 : c1;
+            bool h = side == 0 ? h0 : h1;
+            if (h && c < 0)
+            {
+                int enc = ~c, first = enc >> 3, cnt = (enc & 7) + 1;
+                for (int k = first; k < first + cnt; k++)
+                {
+                    R t;
+                    if (tri_test(S.tri_pre + (size_t)k * 12, p1, dir, t) && t < dist - self_eps && t > self_eps)
+                        return false;
+                }
+            }
+        }
+        bool i0 = h0 && c0 >= 0, i1 = h1 && c1 >= 0;
+        if (i0 && i1)
+        {
+            if (sp < BVH_STACK)
+                stk[sp * lane_stride] = c1;
+            sp++;
+            node = c0;
+        }
+        else if (i0)
+            node = c0;
+        else if (i1)
+            node = c1;
+        else
+        {
+            if (sp == 0)
+                break;
+            sp--;
+            node = stk[sp * lane_stride];
+        }
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// camera rays
+// ---------------------------------------------------------------------------------------------
+template <class R> __device__ __forceinline__ void primary_ray(const DCamera &cam, int x, int y, V3<R> &o, V3<R> &d)
+{
+    // always in double: the matrix comes from a float view matrix but is applied in double
+    double v0 = double(x), v1 = double(y);
+    double p[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+    {
+        double s = cam.m[i * 4 + 0] * v0;
+        s += cam.m[i * 4 + 1] * v1;
+        s += cam.m[i * 4 + 2] * 1.0;
+        s += cam.m[i * 4 + 3] * 1.0;
+        p[i] = s;
+    }
+    V3<double> g = {p[0] - cam.pos[0], p[1] - cam.pos[1], p[2] - cam.pos[2]};
+    V3<double> n = normalized(g);
+    o = {R(cam.pos[0]), R(cam.pos[1]), R(cam.pos[2])};
+    d = {R(n.x), R(n.y), R(n.z)};
+}
+
+// writes the camera rays of the whole image to host-visible buffers (test / operator form)
+__global__ void __launch_bounds__(BLOCK) k_camera_rays(DCamera cam, double *__restrict__ ro, double *__restrict__ rd)
+{
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    int64_t n = (int64_t)cam.width * cam.height;
+    if (i >= n)
+        return;
+    V3<double> o, d;
+    primary_ray<double>(cam, int(i % cam.width), int(i / cam.width), o, d);
+    ro[i * 3] = o.x, ro[i * 3 + 1] = o.y, ro[i * 3 + 2] = o.z;
+    rd[i * 3] = d.x, rd[i * 3 + 1] = d.y, rd[i * 3 + 2] = d.z;
+}
+
+// closest hit of arbitrary rays (AoS double in, face id + point out).  from_camera: generate the
+// ray of pixel i instead of reading it.
+template <class R, bool BRUTE>
+__global__ void __launch_bounds__(BLOCK)
+    k_raycast(DScene<R> S, DCamera cam, int from_camera, const double *__restrict__ ro, const double *__restrict__ rd,
+              int64_t n, int32_t *__restrict__ face_ids, double *__restrict__ pts)
+{
+    __shared__ int stk[BRUTE ? 1 : BVH_STACK * BLOCK];
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    V3<R> o, d;
+    if (from_camera)
+        primary_ray<R>(cam, int(i % cam.width), int(i / cam.width), o, d);
+    else
+    {
+        o = {R(ro[i * 3]), R(ro[i * 3 + 1]), R(ro[i * 3 + 2])};
+        d = {R(rd[i * 3]), R(rd[i * 3 + 1]), R(rd[i * 3 + 2])};
+    }
+    V3<R> p = {R(0), R(0), R(0)};
+    int k = closest_hit<R, BRUTE>(S, o, d, p, stk + threadIdx.x);
+    face_ids[i] = k < 0 ? -1 : S.tri_face[k];
+    if (pts)
+    {
+        const double qn = __builtin_nan("");
+        pts[i * 3] = k < 0 ? qn : double(p.x);
+        pts[i * 3 + 1] = k < 0 ? qn : double(p.y);
+        pts[i * 3 + 2] = k < 0 ? qn : double(p.z);
+    }
+}
+
+template <class R, bool BRUTE>
+__global__ void __launch_bounds__(BLOCK)
+    k_vistest(DScene<R> S, const double *__restrict__ p1, const double *__restrict__ p2, int64_t n, int32_t *__restrict__ vis)
+{
+    __shared__ int stk[BRUTE ? 1 : BVH_STACK * BLOCK];
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    V3<R> a = {R(p1[i * 3]), R(p1[i * 3 + 1]), R(p1[i * 3 + 2])};
+    V3<R> b = {R(p2[i * 3]), R(p2[i * 3 + 1]), R(p2[i * 3 + 2])};
+    vis[i] = visible<R, BRUTE>(S, a, b, stk + threadIdx.x) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wavefront kernels
+// ---------------------------------------------------------------------------------------------
+template <class R> __global__ void __launch_bounds__(BLOCK) k_raygen(DCamera cam, DBatch B, DState<R> st)
+{
+    int64_t pid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (pid >= B.n_paths)
+        return;
+    int64_t pix = pid % B.n_pix;
+    int lr = B.row0 + int(pix / B.n_cols), col = B.col0 + int(pix % B.n_cols);
+    int row = local_row_to_image_row(B, lr);
+    V3<R> o, d;
+    primary_ray<R>(cam, col, row, o, d);
+    st.ray_o[0][0][pid] = o.x, st.ray_o[0][1][pid] = o.y, st.ray_o[0][2][pid] = o.z;
+    st.ray_d[0][0][pid] = d.x, st.ray_d[0][1][pid] = d.y, st.ray_d[0][2][pid] = d.z;
+    st.q_pid[0][pid] = uint32_t(pid);
+    st.path_state[pid] = uint32_t(B.depth) << 16; // default: survives every bounce, zero tail
+    if (pid == 0)
+    {
+        st.counters[0] = uint32_t(B.n_paths);
+        atomicAdd(&st.stats[2], (unsigned long long)B.n_paths);
+    }
+}
+
+template <class R, bool BRUTE> __global__ void __launch_bounds__(BLOCK) k_extend(DScene<R> S, DState<R> st, int bounce)
+{
+    __shared__ int stk[BRUTE ? 1 : BVH_STACK * BLOCK];
+    const int q = bounce & 1;
+    const uint32_t count = st.counters[bounce];
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count)
+        return;
+    V3<R> o = {st.ray_o[q][0][i], st.ray_o[q][1][i], st.ray_o[q][2][i]};
+    V3<R> d = {st.ray_d[q][0][i], st.ray_d[q][1][i], st.ray_d[q][2][i]};
+    V3<R> p = {R(0), R(0), R(0)};
+    int k = closest_hit<R, BRUTE>(S, o, d, p, stk + threadIdx.x);
+    st.hit_prim[i] = k;
+    st.hit_pt[0][i] = p.x, st.hit_pt[1][i] = p.y, st.hit_pt[2][i] = p.z;
+    if (i == 0)
+        atomicAdd(&st.stats[0], (unsigned long long)count);
+}
+
+// appends `alive` lanes to a queue: returns the slot (or -1).  wave64 ballot + popcount prefix,
+// wave totals combined in LDS, ONE global atomic per workgroup.  Must be called by all threads.
+__device__ __forceinline__ int64_t queue_append(bool alive, uint32_t *counter, uint32_t *lds /*[6]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long m = __ballot(alive);
+    int prefix = __popcll(m & ((1ull << lane) - 1ull));
+    int total = __popcll(m);
+    if (lane == 0)
+        lds[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t t0 = lds[0], t1 = lds[1], t2 = lds[2], t3 = lds[3];
+        uint32_t sum = t0 + t1 + t2 + t3;
+        uint32_t base = sum ? atomicAdd(counter, sum) : 0u;
+        lds[0] = base;
+        lds[1] = base + t0;
+        lds[2] = base + t0 + t1;
+        lds[3] = base + t0 + t1 + t2;
+    }
+    __syncthreads();
+    int64_t slot = alive ? int64_t(lds[wave]) + prefix : int64_t(-1);
+    __syncthreads(); // lds is reused by the next call
+    return slot;
+}
+
+template <class R> __global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S, DBatch B, DState<R> st, int bounce)
+{
+    __shared__ uint32_t lds[8];
+    const int q = bounce & 1, qn = q ^ 1;
+    const uint32_t count = st.counters[bounce];
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = i < count;
+    if ((int64_t)blockIdx.x * BLOCK >= count)
+        return; // whole workgroup idle
+    const int64_t N = st.N;
+
+    bool alive = false, defer = false;
+    uint32_t pid = 0, mask = 0;
+    V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
+
+    if (active)
+    {
+        pid = st.q_pid[q][i];
+        const int k = st.hit_prim[i];
+        const int face = k < 0 ? -1 : S.tri_face[k];
+        const int mat_id = face < 0 ? -1 : S.mat_ids[face];
+        if (mat_id < 0)
+            st.path_state[pid] = uint32_t(bounce) << 16; // miss or no material: tail 0
+        else
+        {
+            const R *__restrict__ m = S.mats + (size_t)mat_id * MAT_STRIDE;
+            if (m[13] != R(0))
+                st.path_state[pid] = (uint32_t(bounce) << 16) | uint32_t(mat_id + 1); // emitter: tail Ka
+            else
+            {
+                p = {st.hit_pt[0][i], st.hit_pt[1][i], st.hit_pt[2][i]};
+                V3<R> d = {st.ray_d[q][0][i], st.ray_d[q][1][i], st.ray_d[q][2][i]};
+                const float *__restrict__ vp = S.verts + (size_t)face * 9;
+                V3<R> a = {R(vp[0]), R(vp[1]), R(vp[2])}, b = {R(vp[3]), R(vp[4]), R(vp[5])}, c = {R(vp[6]), R(vp[7]), R(vp[8])};
+                V3<R> n;
+                if (S.enable_bary)
+                {
+                    const float *__restrict__ np = S.normals + (size_t)face * 9;
+                    V3<R> w = barycentric(p, a, b, c);
+                    V3<R> acc = {R(0), R(0), R(0)};
+                    acc = acc + w.x * V3<R>{R(np[0]), R(np[1]), R(np[2])};
+                    acc = acc + w.y * V3<R>{R(np[3]), R(np[4]), R(np[5])};
+                    acc = acc + w.z * V3<R>{R(np[6]), R(np[7]), R(np[8])};
+                    n = normalized(acc);
+                }
+                else
+                    n = normalized(cross(b - a, c - b));
+
+                // which pixel / sample this path belongs to (RNG key)
+                const int64_t pix = int64_t(pid) % B.n_pix;
+                const int s_local = int(int64_t(pid) / B.n_pix);
+                const int lr = B.row0 + int(pix / B.n_cols), col = B.col0 + int(pix % B.n_cols);
+                const uint32_t pixel = uint32_t(local_row_to_image_row(B, lr)) * uint32_t(B.image_width) + uint32_t(col);
+                const uint32_t sample = uint32_t(B.sample0 + s_local);
+                const uint64_t key = rng_pixel_key(B.seed, pixel);
+                const V3<R> wo = -d;
+
+                // NEE over all lights, in order
+                V3<R> direct = {R(0), R(0), R(0)};
+                for (int l = 0; l < S.n_lights; l++)
+                {
+                    const R *__restrict__ L = S.lights + (size_t)l * LIGHT_STRIDE;
+                    V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
+                    R pdf;
+                    const R x1 = rng_draw<R>(key, sample, bounce, 4 * l + 0);
+                    const R x2 = rng_draw<R>(key, sample, bounce, 4 * l + 1);
+                    const bool square = L[0] == R(0);
+                    if (square)
+                        pdf = square_light_sample(L, p, x1, x2, ro, rd);
+                    else
+                        pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bounce, 4 * l + 2), ro, rd);
+                    V3<R> term = {R(0), R(0), R(0)};
+                    bool valid = false;
+                    if (!(pdf < R(1e-10)))
+                    {
+                        R cn = dot(n, -rd);
+                        if (!(cn < R(0)))
+                        {
+                            V3<R> f = bxdf_eval(m, rd, wo, n);
+                            term = {(L[1] * cn / pdf) * f.x, (L[2] * cn / pdf) * f.y, (L[3] * cn / pdf) * f.z};
+                            valid = true;
+                        }
+                    }
+                    if (S.n_square > 0)
+                    {
+                        R *cdst = st.nee_c + (size_t)l * 3 * N, *pdst = st.nee_p1 + (size_t)l * 3 * N;
+                        cdst[i] = term.x, cdst[N + i] = term.y, cdst[2 * N + i] = term.z;
+                        pdst[i] = ro.x, pdst[N + i] = ro.y, pdst[2 * N + i] = ro.z;
+                    }
+                    if (valid && square)
+                        mask |= 1u << l;
+                    direct = direct + term;
+                }
+                defer = mask != 0;
+                if (!defer)
+                {
+                    R *D = st.stack_d + (size_t)bounce * 3 * N;
+                    D[pid] = direct.x, D[N + pid] = direct.y, D[2 * N + pid] = direct.z;
+                }
+                // next direction
+                V3<R> coef = {R(0), R(0), R(0)};
+                if (S.enable_indirect)
+                {
+                    const R x1 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 0);
+                    const R x2 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 1);
+                    bxdf_sample(m, n, wo, x1, x2, wi, coef);
+                    alive = bounce + 1 < B.depth;
+                }
+                else
+                    st.path_state[pid] = uint32_t(bounce + 1) << 16;
+                R *C = st.stack_c + (size_t)bounce * 3 * N;
+                C[pid] = coef.x, C[N + pid] = coef.y, C[2 * N + pid] = coef.z;
+            }
+        }
+    }
+
+    // survivors -> next queue
+    int64_t slot = queue_append(alive, &st.counters[bounce + 1], lds);
+    if (alive)
+    {
+        st.ray_o[qn][0][slot] = p.x, st.ray_o[qn][1][slot] = p.y, st.ray_o[qn][2][slot] = p.z;
+        st.ray_d[qn][0][slot] = wi.x, st.ray_d[qn][1][slot] = wi.y, st.ray_d[qn][2][slot] = wi.z;
+        st.q_pid[qn][slot] = pid;
+    }
+    // paths with NEE terms that need a visibility test -> shadow list
+    if (S.n_square > 0)
+    {
+        int64_t ns = queue_append(defer, &st.counters[B.depth + 1 + bounce], lds);
+        if (defer)
+        {
+            st.nee_idx[ns] = uint32_t(i);
+            st.nee_mask[i] = mask;
+        }
+    }
+}
+
+template <class R, bool BRUTE> __global__ void __launch_bounds__(BLOCK) k_shadow(DScene<R> S, DBatch B, DState<R> st, int bounce)
+{
+    __shared__ int stk[BRUTE ? 1 : BVH_STACK * BLOCK];
+    const uint32_t count = st.counters[B.depth + 1 + bounce];
+    const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= count)
+        return;
+    const int64_t N = st.N;
+    const uint32_t i = st.nee_idx[j];
+    const uint32_t pid = st.q_pid[bounce & 1][i], mask = st.nee_mask[i];
+    const V3<R> p2 = {st.hit_pt[0][i], st.hit_pt[1][i], st.hit_pt[2][i]};
+    V3<R> direct = {R(0), R(0), R(0)};
+    const int nl = S.n_lights;
+    unsigned long long tests = 0;
+    for (int l = 0; l < nl; l++)
+    {
+        const R *csrc = st.nee_c + (size_t)l * 3 * N;
+        V3<R> term = {csrc[i], csrc[N + i], csrc[2 * N + i]};
+        if (mask & (1u << l))
+        {
+            const R *psrc = st.nee_p1 + (size_t)l * 3 * N;
+            V3<R> p1 = {psrc[i], psrc[N + i], psrc[2 * N + i]};
+            tests++;
+            if (!visible<R, BRUTE>(S, p1, p2, stk + threadIdx.x))
+                continue;
+        }
+        direct = direct + term;
+    }
+    R *D = st.stack_d + (size_t)bounce * 3 * N;
+    D[pid] = direct.x, D[N + pid] = direct.y, D[2 * N + pid] = direct.z;
+    // one atomic per wave for the shadow-ray statistic
+    for (int off = 32; off > 0; off >>= 1)
+        tests += __shfl_down(tests, off, 64);
+    if ((threadIdx.x & 63) == 0 && tests)
+        atomicAdd(&st.stats[1], tests);
+}
+
+// one thread per pixel of the batch: resolves its samples in order and continues the running sum
+template <class R> __global__ void __launch_bounds__(BLOCK) k_resolve(DScene<R> S, DBatch B, DState<R> st, double *__restrict__ sum, int image_width)
+{
+    const int64_t pix = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (pix >= B.n_pix)
+        return;
+    const int64_t N = st.N;
+    const int lr = B.row0 + int(pix / B.n_cols), col = B.col0 + int(pix % B.n_cols);
+    const int row = local_row_to_image_row(B, lr);
+    double *dst = sum + ((int64_t)row * image_width + col) * 3;
+    double cr = dst[0], cg = dst[1], cb = dst[2];
+    for (int s = 0; s < B.n_samples; s++)
+    {
+        const int64_t pid = (int64_t)s * B.n_pix + pix;
+        const uint32_t ps = st.path_state[pid];
+        const int len = int(ps >> 16), tm = int(ps & 0xffff);
+        R fr = R(0), fg = R(0), fb = R(0);
+        if (tm)
+        {
+            const R *m = S.mats + (size_t)(tm - 1) * MAT_STRIDE;
+            fr = m[0], fg = m[1], fb = m[2];
+        }
+        for (int i = len - 1; i >= 0; i--)
+        {
+            const R *D = st.stack_d + (size_t)i * 3 * N, *C = st.stack_c + (size_t)i * 3 * N;
+            fr = D[pid] + C[pid] * fr;
+            fg = D[N + pid] + C[N + pid] * fg;
+            fb = D[2 * N + pid] + C[2 * N + pid] * fb;
+            R mx = fr;
+            if (fg > mx)
+                mx = fg;
+            if (fb > mx)
+                mx = fb;
+            if (R(0) > mx)
+                mx = R(0);
+            if (mx > R(1))
+                fr /= mx, fg /= mx, fb /= mx;
+        }
+        cr += double(fr) / B.spp_total;
+        cg += double(fg) / B.spp_total;
+        cb += double(fb) / B.spp_total;
+    }
+    dst[0] = cr, dst[1] = cg, dst[2] = cb;
+}
+
+} // namespace ptx

@@ -1,0 +1,91 @@
+// Headless command line: `pathtracer <conf> [overrides]`, the process-level contract of the
+// reference binary (src/main.cpp:28-53 of the reference: exactly one conf argument, paths inside
+// the conf relative to the working directory, "[error] ..." on stdout and exit code 1 on failure,
+// ASCII PPM written to PathTracer.ResultPath).
+#include "../../include/ptx.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static int die(const char *what)
+{
+    std::printf("[error] %s: %s\n", what, ptx_last_error());
+    return 1;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2)
+    {
+        std::printf("[error] usage: pathtracer <conf> [--width W] [--height H] [--spp N] [--depth D] [--out PATH] "
+                    "[--mode f64|f32] [--gpu ID] [--seed S] [--root DIR] [--model OBJ]\n");
+        return 1;
+    }
+    ptx_overrides ov;
+    std::memset(&ov, 0, sizeof(ov));
+    ptx_render_opts ro;
+    std::memset(&ro, 0, sizeof(ro));
+    ro.seed = 13;
+    std::string out_path, root;
+    int gpu = 0;
+    for (int i = 2; i < argc; i++)
+    {
+        std::string a = argv[i];
+        auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
+        if (a == "--width")
+            ov.width = std::atoi(next());
+        else if (a == "--height")
+            ov.height = std::atoi(next());
+        else if (a == "--spp")
+            ov.spp = std::atoi(next());
+        else if (a == "--depth")
+            ov.depth = std::atoi(next());
+        else if (a == "--out")
+            out_path = next();
+        else if (a == "--root")
+            root = next();
+        else if (a == "--model")
+            ov.model = next();
+        else if (a == "--gpu")
+            gpu = std::atoi(next());
+        else if (a == "--seed")
+            ro.seed = std::strtoull(next(), nullptr, 10);
+        else if (a == "--mode")
+            ro.mode = std::string(next()) == "f32" ? PTX_MODE_F32 : PTX_MODE_F64;
+        else
+        {
+            std::printf("[error] unknown option %s\n", a.c_str());
+            return 1;
+        }
+    }
+    ptx_scene *scene = nullptr;
+    if (ptx_scene_load_conf(argv[1], root.empty() ? nullptr : root.c_str(), &ov, &scene))
+        return die("load conf");
+    ptx_scene_info info;
+    ptx_scene_get_info(scene, &info);
+    std::printf("[log] scene: %d faces, %d materials, %d lights, %dx%d, %d spp, depth %d\n", info.n_tris, info.n_mats,
+                info.n_lights, info.width, info.height, info.spp, info.depth);
+    ptx_context *ctx = nullptr;
+    if (ptx_context_create(gpu, &ctx))
+        return die("create context");
+    if (ptx_build_accel(ctx, scene))
+        return die("build accel");
+    std::vector<double> sum(static_cast<size_t>(info.width) * info.height * 3), img(sum.size());
+    ptx_stats st;
+    if (ptx_render(ctx, &ro, sum.data(), 0, &st))
+        return die("render");
+    std::printf("[log] cPathTracer::RayCast end, cost time = %.3f ms, %.3f Mpaths/s, %.3f Mrays/s\n", st.ms_total,
+                st.paths / st.ms_total * 1e-3, (st.segments + st.shadow_rays) / st.ms_total * 1e-3);
+    ptx_finalize_image(sum.data(), static_cast<int64_t>(info.width) * info.height, img.data());
+    if (out_path.empty())
+        out_path = ptx_scene_result_path(scene);
+    if (ptx_write_ppm(out_path.c_str(), img.data(), info.width, info.height))
+        return die("write ppm");
+    std::printf("[debug] output img to %s, finished\n", out_path.c_str());
+    ptx_context_destroy(ctx);
+    ptx_scene_destroy(scene);
+    return 0;
+}
