@@ -103,6 +103,9 @@ void ptx_scene_destroy(ptx_scene *);
  * src/geometry/cObjMesh.h, src/render/camera/cBaseCamera.hpp:26-31). Null outputs are skipped. */
 int ptx_scene_get_info(const ptx_scene *, ptx_scene_info *out);
 int ptx_scene_copy_geometry(const ptx_scene *, float *verts, float *normals, int32_t *mat_ids);
+/* OBJ vertex index (0-based) of every face corner, [n_tris][3]: tFace::mVertexIdList,
+ * src/geometry/cBaseMesh.h:76 (what the reference's .edge tables are built from). */
+int ptx_scene_copy_vertex_ids(const ptx_scene *, int32_t *vertex_ids);
 int ptx_scene_copy_tables(const ptx_scene *, double *mats12, double *lights16);
 int ptx_scene_copy_camera(const ptx_scene *, double *view16, double *cam_pos3, double *raster2world16);
 const char *ptx_scene_result_path(const ptx_scene *);

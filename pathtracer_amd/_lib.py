@@ -54,6 +54,7 @@ SYMBOLS = {
     "ptx_scene_destroy": (None, [_VP]),
     "ptx_scene_get_info": (C.c_int, [_VP, C.POINTER(SceneInfo)]),
     "ptx_scene_copy_geometry": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "ptx_scene_copy_vertex_ids": (C.c_int, [_VP, _VP]),
     "ptx_scene_copy_tables": (C.c_int, [_VP, _VP, _VP]),
     "ptx_scene_copy_camera": (C.c_int, [_VP, _VP, _VP, _VP]),
     "ptx_scene_result_path": (C.c_char_p, [_VP]),

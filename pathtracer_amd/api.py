@@ -84,6 +84,11 @@ class Scene:
         check(_lib.lib().ptx_scene_copy_geometry(self._h, _ptr(verts), _ptr(normals), _ptr(mat_ids)))
         return verts, normals, mat_ids
 
+    def vertex_ids(self):
+        ids = np.zeros((self.info.n_tris, 3), dtype=np.int32)
+        check(_lib.lib().ptx_scene_copy_vertex_ids(self._h, _ptr(ids)))
+        return ids
+
     def tables(self):
         i = self.info
         mats = np.zeros((i.n_mats, 12))

@@ -194,6 +194,14 @@ int ptx_scene_copy_geometry(const ptx_scene *s, float *verts, float *normals, in
     return PTX_OK;
 }
 
+int ptx_scene_copy_vertex_ids(const ptx_scene *s, int32_t *vertex_ids)
+{
+    if (!s || !vertex_ids)
+        return fail_arg("ptx_scene_copy_vertex_ids: null argument");
+    std::memcpy(vertex_ids, s->sc.vert_ids.data(), s->sc.vert_ids.size() * sizeof(int32_t));
+    return PTX_OK;
+}
+
 int ptx_scene_copy_tables(const ptx_scene *s, double *mats12, double *lights16)
 {
     if (!s)

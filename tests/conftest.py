@@ -1,0 +1,44 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """The oracle (gcc) is cheap to build, so make sure it exists; the HIP library is built by
+    __graft_entry__.build() / `make -C pathtracer_amd/csrc` beforehand and only checked here."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    if not os.path.exists(os.path.join(ROOT, "scenes", "cbox", "cbox.obj")):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_scenes.py"), "--only", "cbox,mis"])
+    yield
+
+
+@pytest.fixture(scope="session")
+def root():
+    return ROOT
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def room_scene():
+    """The ~250 k-triangle room stand-in is generated on demand (25 MB, not committed)."""
+    p = os.path.join(ROOT, "scenes", "room", "room.obj")
+    if not os.path.exists(p):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_scenes.py"), "--only", "room"])
+    return p

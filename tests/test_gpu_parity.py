@@ -1,0 +1,282 @@
+"""GPU parity tests (run on an MI355X with -m gpu).  Everything goes through the C ABI of
+libptx_amd.so and is compared with the CPU oracle on the same seeded inputs.
+
+Bars: camera rays, first-hit face ids, hit points and visibility flags are BIT-EXACT.  Images in
+f64 mode use the reference's arithmetic with the same random numbers, so they agree with the oracle
+up to the last-ulp differences between the device's and glibc's pow/acos/sin/cos: tolerance
+1e-9 absolute on the pre-clamp sums with identical ray counts.  Images in f32 mode must satisfy the
+relative-MSE bar  rMSE <= max(2 x rMSE(oracle seed A, oracle seed B), 1e-3)  at equal spp."""
+import os
+
+import numpy as np
+import pytest
+
+import pathtracer_amd as pt
+from oracle import oracle, scene_io
+
+pytestmark = pytest.mark.gpu
+F64_TOL = 1e-9
+
+
+def assert_f64_parity(img, oimg, st=None, ost=None, depth=15):
+    """f64 images must agree to F64_TOL in (nearly) every pixel.  The few exceptions allowed are
+    paths whose continuation hinges on an exact geometric tie: the Cornell box asset has two
+    coplanar, oppositely wound quads in the ceiling (the light-hole cover), and which of them wins
+    a closest-hit tie is decided by the last ulp of the ray direction -- where the device's and
+    glibc's sin/cos/acos may differ.  Such a path is a different, equally valid sample."""
+    diff = np.abs(np.asarray(img) - np.asarray(oimg)).max(axis=-1)
+    n_pix = diff.size
+    allowed = max(2, n_pix // 500)
+    bad = int((diff > F64_TOL).sum())
+    assert bad <= allowed, "%d of %d pixels differ by more than %g" % (bad, n_pix, F64_TOL)
+    assert oracle.rmse_rel(img, oimg) < 1e-4
+    if st is not None:
+        assert st["paths"] == ost["paths"]
+        assert abs(int(st["segments"]) - int(ost["segments"])) <= depth * bad
+    return bad
+
+
+def load(root, conf, **kw):
+    s = pt.Scene.load_conf(os.path.join(root, conf), root_dir=root, **kw)
+    ref = scene_io.load_conf(os.path.join(root, conf), root_dir=root, **kw)
+    return s, ref
+
+
+def make_ctx(scene, **kw):
+    c = pt.Context(0, **kw)
+    c.build_accel(scene)
+    return c
+
+
+@pytest.fixture(scope="module")
+def cbox64(root):
+    s, ref = load(root, "config/cbox.conf", width=64, height=64, spp=8)
+    return s, ref, make_ctx(s), oracle.Oracle(ref, seed=13)
+
+
+def test_camera_rays_bit_exact(cbox64):
+    s, ref, c, O = cbox64
+    o, d = c.generate_rays()
+    oo, od = O.generate_rays()
+    assert np.array_equal(o, oo) and np.array_equal(d, od)
+
+
+def test_first_hit_ids_bit_exact_small(cbox64, golden):
+    s, ref, c, O = cbox64
+    ids, pts = c.first_hit(with_points=True)
+    oids, opts = O.first_hit(with_points=True)
+    assert np.array_equal(ids, oids)
+    assert np.array_equal(pts, opts, equal_nan=True)
+    g = np.load(os.path.join(golden, "cbox_first_hit.npz"))
+    assert np.array_equal(ids, g["ids_64"].astype(np.int32))
+
+
+@pytest.mark.parametrize("w", [256, 1024])
+def test_first_hit_ids_bit_exact_full_size(root, golden, w):
+    s, ref = load(root, "config/cbox.conf", width=w, height=w, spp=1)
+    c = make_ctx(s)
+    ids, pts = c.first_hit(with_points=True)
+    oids, opts = oracle.Oracle(ref).first_hit(with_points=True)
+    assert int((ids != oids).sum()) == 0
+    assert np.array_equal(pts, opts, equal_nan=True)
+    if w == 256:
+        g = np.load(os.path.join(golden, "cbox_first_hit.npz"))
+        assert np.array_equal(ids, g["ids_256"].astype(np.int32))
+
+
+def random_rays(n, seed):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(0.05, 5.4, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # a share of rays start ON surfaces (the secondary-ray situation)
+    o[: n // 4, 1] = 0.0
+    d[: n // 4, 1] = np.abs(d[: n // 4, 1])
+    return o, d
+
+
+def test_raycast_and_vistest_operators_bit_exact(cbox64):
+    s, ref, c, O = cbox64
+    o, d = random_rays(20000, 1)
+    ids, pts = c.raycast(o, d)
+    for i in range(0, 20000, 7):                      # oracle is scalar: check a strided subset
+        f, p = O.closest_hit(o[i], d[i])
+        assert f == ids[i] and np.array_equal(p, pts[i], equal_nan=True)
+    rng = np.random.default_rng(2)
+    p1 = np.tile(np.array([2.78, 5.48, 2.795]), (6000, 1)) + rng.uniform(-0.6, 0.6, (6000, 3)) * [1, 0, 1]
+    p2 = rng.uniform(0.0, 5.4, (6000, 3))
+    p2[:2000, 1] = 0.0
+    p2[5990:] = p1[5990:]                            # zero-length segments are visible
+    vis = c.vistest(p1, p2)
+    ovis = np.array([O.vistest(a, b) for a, b in zip(p1, p2)])
+    assert np.array_equal(vis, ovis) and 0.05 < vis.mean() < 0.98
+
+
+def test_bvh_traversal_equals_brute_force(root):
+    s, ref = load(root, "config/cbox.conf", width=128, height=128, spp=4)
+    brute, bvh = make_ctx(s), make_ctx(s, brute_force_limit=0)
+    assert brute.accel_info()["brute_force"] and not bvh.accel_info()["brute_force"]
+    a, pa = brute.first_hit(with_points=True)
+    b, pb = bvh.first_hit(with_points=True)
+    assert np.array_equal(a, b) and np.array_equal(pa, pb, equal_nan=True)
+    o, d = random_rays(50000, 3)
+    ia, qa = brute.raycast(o, d)
+    ib, qb = bvh.raycast(o, d)
+    assert np.array_equal(ia, ib) and np.array_equal(qa, qb, equal_nan=True)
+    ia_, sa = brute.render(mode="f64")
+    ib_, sb = bvh.render(mode="f64")
+    assert np.array_equal(ia_, ib_) and sa["segments"] == sb["segments"]
+
+
+def test_render_f64_matches_golden_image(root, golden):
+    g = np.load(os.path.join(golden, "cbox_32_spp16.npz"))
+    s, ref = load(root, "config/cbox.conf", width=32, height=32, spp=16)
+    img, st = make_ctx(s).render(mode="f64", seed=13)
+    ost = dict(paths=int(g["stats"][0]), segments=int(g["stats"][1]))
+    assert_f64_parity(img, g["img"], st, ost)
+
+
+@pytest.mark.parametrize("conf,w,h,spp", [("config/cbox.conf", 64, 64, 8), ("config/cbox_glossy.conf", 48, 48, 8),
+                                          ("config/cbox_cube.conf", 48, 48, 8), ("config/mis.conf", 96, 64, 4)])
+def test_render_f64_matches_oracle(root, conf, w, h, spp):
+    s, ref = load(root, conf, width=w, height=h, spp=spp)
+    img, st = make_ctx(s).render(mode="f64", seed=13)
+    oimg, ost = oracle.Oracle(ref, seed=13).render(stats=True)
+    assert st["paths"] == w * h * spp
+    assert_f64_parity(img, oimg, st, ost, depth=ref.depth)
+
+
+def test_render_flags_and_region(root):
+    for kw in (dict(enable_indirect=False), dict(enable_bary_normal=False), dict(region=(5, 7, 20, 30))):
+        s, ref = load(root, "config/cbox.conf", width=40, height=40, spp=4)
+        for k, v in kw.items():
+            setattr(ref, k, v)
+        verts, normals, mat_ids = s.geometry()
+        mats, lights = s.tables()
+        s2 = pt.Scene.from_arrays(verts, normals, mat_ids, mats, lights, ref.view, ref.cam_pos, ref.fov_deg, ref.near,
+                                  40, 40, ref.depth, 4, ref.enable_indirect, ref.enable_bary_normal)
+        c = make_ctx(s2)
+        rows = None
+        oimg = oracle.Oracle(ref, seed=13).render()
+        if "region" in kw:
+            # rows through the render options; columns are checked by masking the oracle image
+            rows = (5, 21)
+            ref.region = (5, 0, 20, 40)
+            oimg = oracle.Oracle(ref, seed=13).render()
+        img, st = c.render(mode="f64", rows=rows)
+        assert_f64_parity(img, oimg)
+        if "region" in kw:
+            assert (img[:5] == 0).all() and (img[21:] == 0).all()
+
+
+def test_draw_region_from_conf(root, tmp_path):
+    import json
+    conf = json.load(open(os.path.join(root, "config/cbox.conf")))
+    conf["MainWindowInfo"]["Width"] = conf["MainWindowInfo"]["Height"] = 36
+    conf["PathTracer"]["DrawRegion"] = [3, 5, 17, 29]
+    conf["PathTracer"]["Samples"] = 3
+    p = tmp_path / "r.conf"
+    p.write_text(json.dumps(conf))
+    s = pt.Scene.load_conf(str(p), root_dir=root)
+    ref = scene_io.load_conf(str(p), root_dir=root, full_region=False)
+    assert tuple(ref.region) == (3, 5, 17, 29)
+    img, _ = make_ctx(s).render(mode="f64")
+    oimg = oracle.Oracle(ref, seed=13).render()
+    assert_f64_parity(img, oimg)
+    mask = np.zeros((36, 36), bool)
+    mask[3:18, 5:30] = True
+    assert (img[~mask] == 0).all()
+
+
+def test_batching_sharding_and_bands_are_bit_invariant(cbox64):
+    s, ref, c, O = cbox64
+    full, st = c.render(mode="f64", spp=8)
+    # many small batches (row chunks x sample batches) -> identical sums
+    small, st2 = c.render(mode="f64", spp=8, batch_paths=64 * 5 * 3)
+    assert st2["passes"] > 10 and np.array_equal(full, small)
+    # sample-range sharding, accumulated in order -> identical; summed separately -> 1 ulp
+    acc, _ = c.render(mode="f64", spp=4, sample_offset=0, spp_total=8)
+    acc, _ = c.render(mode="f64", spp=4, sample_offset=4, spp_total=8, accumulate=True, out=acc)
+    assert np.array_equal(acc, full)
+    lo, _ = c.render(mode="f64", spp=4, sample_offset=0, spp_total=8)
+    hi, _ = c.render(mode="f64", spp=4, sample_offset=4, spp_total=8)
+    assert np.allclose(lo + hi, full, rtol=0, atol=1e-14)
+    # interleaved row bands (the multi-GPU tile sharding): disjoint supports, exact union
+    parts = [c.render(mode="f64", spp=8, row_stride=3, row_phase=k, band=4)[0] for k in range(3)]
+    assert np.array_equal(parts[0] + parts[1] + parts[2], full)
+    rows = np.arange(64)
+    for k in range(3):
+        assert (parts[k][(rows // 4) % 3 != k] == 0).all()
+
+
+def test_render_f32_meets_rmse_bar(root):
+    s, ref = load(root, "config/cbox.conf", width=64, height=64, spp=16)
+    c = make_ctx(s)
+    a = oracle.Oracle(ref, seed=13).render()
+    b = oracle.Oracle(ref, seed=14).render()
+    tol = max(2 * oracle.rmse_rel(b, a), 1e-3)
+    img, st = c.render(mode="f32", seed=13)
+    assert oracle.rmse_rel(img, a) <= tol
+    # an independent seed must also sit inside the statistical bar
+    img2, _ = c.render(mode="f32", seed=99)
+    assert oracle.rmse_rel(img2, a) <= tol
+    # and the f32 path length statistics stay those of the reference estimator
+    _, ost = oracle.Oracle(ref, seed=13).render(stats=True)
+    assert abs(st["segments"] / ost["segments"] - 1) < 0.01
+
+
+def test_full_size_properties(root):
+    """BASELINE size (1024 x 1024): properties that need no CPU render."""
+    s, ref = load(root, "config/cbox.conf", width=1024, height=1024, spp=4)
+    c = make_ctx(s)
+    a, sa = c.render(mode="f64", spp=4)
+    b, sb = c.render(mode="f64", spp=4, batch_paths=1 << 19)
+    assert np.array_equal(a, b) and sa["segments"] == sb["segments"] and sb["passes"] > sa["passes"]
+    ids = c.first_hit()
+    lit = ((ids == 10) | (ids == 11)).reshape(1024, 1024)
+    assert np.array_equal(a[lit], np.full((lit.sum(), 3), 10.0))       # emitter seen directly: Ka, unclamped
+    assert a[~lit].max() <= 1.0 + 1e-12                                 # every other sample is clamped to 1
+    assert (a[(ids == -1).reshape(1024, 1024)] == 0).all()              # misses are black
+    fin = pt.finalize_image(a)
+    assert fin.max() <= 1.0 and fin.min() >= 0
+    f32, _ = c.render(mode="f32", spp=4)
+    assert oracle.rmse_rel(f32, a) < 1e-3
+    # a crop of the full-size image against the oracle rendering only that window
+    ref.region = (500, 480, 515, 543)
+    oimg = oracle.Oracle(ref, seed=13).render()
+    assert_f64_parity(a[500:516, 480:544], oimg[500:516, 480:544])
+
+
+def test_pathtracer_process_writes_reference_format_ppm(root, tmp_path):
+    import json
+    conf = json.load(open(os.path.join(root, "config/cbox.conf")))
+    conf["MainWindowInfo"]["Width"] = conf["MainWindowInfo"]["Height"] = 24
+    conf["PathTracer"]["DrawRegion"] = [0, 0, 24, 24]
+    conf["PathTracer"]["Samples"] = 4
+    conf["PathTracer"]["ResultPath"] = str(tmp_path / "out.ppm")
+    p = tmp_path / "c.conf"
+    p.write_text(json.dumps(conf))
+    tracer = pt.PathTracer(str(p), root_dir=root)
+    with pytest.raises(pt.PtxError):
+        tracer.Process()                                   # Process before Init is an error
+    tracer.Init()
+    img = tracer.Process()
+    ref = scene_io.load_conf(str(p), root_dir=root)
+    ofin = oracle.finalize(oracle.Oracle(ref, seed=13).render())
+    got = pt.read_ppm(str(tmp_path / "out.ppm"))
+    want = (ofin * 255).astype(np.int64)
+    assert got.shape == (24, 24, 3)
+    assert (np.abs(got - want) <= 1).all() and (got != want).mean() < 0.01   # int(c*255) truncation
+    text = open(tmp_path / "out.ppm").read()
+    assert text.startswith("P3\n24 24\n255\n") and text.count("\n") == 3
+
+
+def test_errors_cross_the_boundary_as_codes(root):
+    c = pt.Context(0)
+    with pytest.raises(pt.PtxError) as e:
+        c.width = c.height = 4
+        c.first_hit()
+    assert e.value.code == 5                                # no scene yet
+    with pytest.raises(pt.PtxError) as e:
+        pt.Context(99)
+    assert e.value.code == 1
