@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpaths/s on the Cornell box at 1024 x 1024, 256 spp per GPU.
+
+One "step" = one full pass of the hot path over the workload: camera rays, 15 bounces of
+extend / shade / shadow, resolve -- i.e. cPathTracer::Process of the reference for
+config/cbox.conf at 1024 x 1024 x 256 spp (BASELINE.json configs[1]).  With N GPUs every rank
+renders its own range of 256 samples of the same image (weak scaling: 256 * N spp in total) and the
+per-pixel sums are reduced onto rank 0 over RCCL inside the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode f64|f32] [--spp S] [--size W]
+
+For N > 1 launch through `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
+Rank 0 prints ONE JSON line.  Inputs are resident in HBM when the timed region starts; the output
+is a device buffer (no PCIe traffic inside the timed region).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, spec
+F64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector FP64 (FMA counted as 2 flop), spec
+F32_VALU_PEAK_TFLOPS = 157.3
+
+
+def algorithmic_bytes(mode, n_lights, n_square):
+    """Bytes each kernel must move per unit of work with ideal caching (scene tables excluded:
+    the 26-triangle scene is read through the scalar cache).  R = size of the scalar type."""
+    R = 8 if mode == "f64" else 4
+    deferred = n_square > 0
+    extend = 6 * R + 4 + 3 * R                      # read ray o,d; write prim id + hit point
+    shade = (4 + 4 + 3 * R + 3 * R + 72             # pid, prim, hit point, ray d, 3 pos + 3 normals (f32)
+             + 3 * R                                # push coefficient
+             + (n_lights * 6 * R + 8 if deferred else 3 * R)   # per-light terms + sample points | direct
+             + 6 * R + 4)                           # next ray + pid
+    shadow = 4 + 4 + 4 + 3 * R + n_lights * 6 * R + 3 * R      # idx, pid, mask, point, terms, write direct
+    return dict(extend=extend, shade=shade, shadow=shadow)
+
+
+def tri_test_flops():
+    return 60.0  # r (3), col1 x d (9), det (5), 1/det (1), beta (8), d x col0 and scale (12), gamma (5), t (8), alpha (2), compares (7)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", default=os.environ.get("PTX_BENCH_MODE", "f64"), choices=["f64", "f32"])
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--conf", default="config/cbox.conf")
+    ap.add_argument("--batch-paths", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import pathtracer_amd as pt
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the path-tracing core has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    W = H = args.size
+    scene = pt.Scene.load_conf(os.path.join(ROOT, args.conf), root_dir=ROOT, width=W, height=H, spp=args.spp)
+    info = scene.info
+    stream = torch.cuda.current_stream()
+    ctx = pt.Context(local_rank, stream=stream.cuda_stream, batch_paths=args.batch_paths or None)
+    ctx.build_accel(scene)
+    out = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+    spp_total = args.spp * world
+
+    from pathtracer_amd.distributed import render_frame
+
+    def render_fn(o, **kw):
+        return ctx.render_device(o.data_ptr(), **kw)
+
+    def step(profile=False, mode=None):
+        # rank r renders samples [r*spp, (r+1)*spp) of every pixel, then RCCL reduce(sum) -> rank 0
+        return render_frame(render_fn, out, spp_total, rank, world, scheme="samples", mode=mode or args.mode,
+                            seed=13, profile=profile)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    paths_per_step = W * H * args.spp * world
+    value = paths_per_step * args.steps / dt / 1e6
+
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: one more step with HIP events around every launch
+        # on the render stream (same workload, same stream; not part of the timed region above)
+        ps = step(profile=True)
+        torch.cuda.synchronize()
+        classes = {"extend": ps["ms_extend"], "shade": ps["ms_shade"], "shadow": ps["ms_shadow"]}
+        dom = max(classes, key=classes.get)
+        launches = int(ps["passes"]) * info.depth
+        units = {"extend": ps["segments"], "shade": ps["segments"], "shadow": ps["shadow_rays"]}
+        ab = algorithmic_bytes(args.mode, info.n_lights, info.n_square_lights)
+        bytes_per_launch = ab[dom] * units[dom] / launches
+        avg_ms = classes[dom] / launches
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        tests_per_unit = info.n_tris  # all-triangles loop of the 26-triangle scene
+        flops = tri_test_flops() * tests_per_unit * units[dom] if dom != "shade" else 0.0
+        peak_t = F64_VALU_PEAK_TFLOPS if args.mode == "f64" else F32_VALU_PEAK_TFLOPS
+        valu_ach = flops / (classes[dom] * 1e-3) / 1e12 if classes[dom] > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "bytes_per_launch": round(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5),
+                    "launches_per_step": launches,
+                    "note": "the all-triangles intersector is VALU-bound, see valu"}
+        valu = {"kernel": "k_" + dom, "achieved": round(valu_ach, 2), "peak": peak_t, "unit": "TFLOP/s",
+                "frac": round(valu_ach / peak_t, 4), "flop_per_tri_test": tri_test_flops(),
+                "note": "non-fused f64 ops count 1 flop each; the spec peak counts FMA as 2"}
+        kernel_ms = {k: round(v, 3) for k, v in classes.items()}
+        kernel_ms["other"] = round(ps["ms_other"], 3)
+
+        # the other precision, one step, for the record
+        other_mode = "f32" if args.mode == "f64" else "f64"
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step(mode=other_mode)
+        torch.cuda.synchronize()
+        other_value = W * H * args.spp / (time.perf_counter() - t1) / 1e6 if world == 1 else None
+
+        cpu = None
+        checks = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu, checks = cpu_baseline_and_checks(ctx, args, W, H)
+
+        result = {
+            "metric": "Mpaths/s at cbox 1024x1024 (whole job, all GPUs)", "value": round(value, 3), "unit": "Mpaths/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.mode, "data": "synthetic",
+            "config": {"workload": "cbox %dx%d, %d spp per GPU, depth %d, 26 triangles, 1 square light "
+                                   "(config/cbox.conf, BASELINE configs[1])" % (W, H, args.spp, info.depth),
+                       "global_spp": spp_total, "paths_per_step": paths_per_step,
+                       "sharding": "sample ranges per rank + RCCL reduce(sum) of the radiance sums to rank 0"},
+            "mrays_per_s": round((st["segments"] + st["shadow_rays"]) * world * args.steps / dt / 1e6, 1),
+            "segments_per_path": round(st["segments"] / st["paths"], 3),
+            "roofline": roofline, "valu": valu, "kernel_ms_per_step": kernel_ms,
+            "other_mode": {"dtype": other_mode, "value": None if other_value is None else round(other_value, 3)},
+            "cpu_baseline": cpu, "checks": checks,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def cpu_baseline_and_checks(ctx, args, W, H):
+    """The CPU oracle (a port of the reference's OpenMP row loop) timed on a bounded sample of the
+    same workload, and the two correctness gates next to the throughput number."""
+    from oracle import oracle, scene_io
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    ref = scene_io.load_conf(os.path.join(ROOT, args.conf), root_dir=ROOT, width=W, height=H, spp=1)
+    O = oracle.Oracle(ref, seed=13)
+    # calibrate on a few rows, then pick the spp that fills the time budget
+    ref_small = scene_io.load_conf(os.path.join(ROOT, args.conf), root_dir=ROOT, width=256, height=256, spp=2)
+    t0 = time.perf_counter()
+    oracle.Oracle(ref_small, seed=13).render(threads=threads)
+    rate = 256 * 256 * 2 / (time.perf_counter() - t0)
+    spp = int(max(1, min(args.spp, round(rate * args.cpu_seconds / (W * H)))))
+    t0 = time.perf_counter()
+    oimg, ost = O.render(spp=spp, threads=threads, stats=True)
+    cpu_dt = time.perf_counter() - t0
+    cpu = {"value": round(W * H * spp / cpu_dt / 1e6, 4), "unit": "Mpaths/s", "cores": threads, "kind": "port",
+           "sample": "cbox %dx%d at %d spp (%.1f s, oracle/pt_oracle.c, OpenMP dynamic over rows, f64, all-triangles loop)"
+                     % (W, H, spp, cpu_dt)}
+    # gates: first-hit ids and the image at equal spp
+    ids = ctx.first_hit()
+    oids = O.first_hit()
+    gimg, _ = ctx.render(mode=args.mode, spp=spp, seed=13)
+    o2 = oracle.Oracle(ref, seed=14).render(spp=spp, threads=threads) if spp <= 4 else None
+    rmse = oracle.rmse_rel(gimg, oimg)
+    floor = oracle.rmse_rel(o2, oimg) if o2 is not None else None
+    checks = {"first_hit_mismatches": int((ids != oids).sum()), "first_hit_pixels": int(ids.size),
+              "rmse_vs_cpu_equal_spp": rmse, "spp": spp,
+              "rmse_tolerance": None if floor is None else max(2 * floor, 1e-3),
+              "oracle_two_seed_rmse": floor}
+    return cpu, checks
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,44 @@
+"""Multi-GPU sharding of one frame: one process per GPU, no collective on the data path, ONE
+exchange at the end (reduce of the per-pixel radiance sums onto rank 0; RCCL over xGMI when the
+process group's backend is "nccl").
+
+The per-pixel value of the reference is  sum_s final_s / spp  followed by one clamp
+(src/tracing/cPathTracer.cpp:692,701-702 of the reference), i.e. linear in the samples before the
+clamp.  So a frame can be cut either by sample ranges (every rank renders all pixels for its own
+samples, images are SUMMED) or by interleaved row bands (disjoint supports, SUM is a union).  Random
+numbers are keyed by the global (pixel, sample) index, so every cut renders the same samples."""
+from __future__ import annotations
+
+
+def shard_samples(spp_total, rank, world):
+    """Contiguous sample range of `rank`: (offset, count); the ranges tile [0, spp_total)."""
+    base, rem = divmod(int(spp_total), int(world))
+    count = base + (1 if rank < rem else 0)
+    offset = rank * base + min(rank, rem)
+    return offset, count
+
+
+def shard_bands(rank, world, band=8):
+    """Interleaved row bands: rank renders rows r with (r // band) % world == rank."""
+    return dict(row_stride=int(world), row_phase=int(rank), band=int(band))
+
+
+def render_frame(render_fn, out, spp_total, rank=0, world=1, scheme="samples", band=8, reduce=True, **kw):
+    """Renders this rank's share into `out` (a torch tensor [H,W,3] float64 on the rank's device)
+    and reduces onto rank 0.  `render_fn(out, **options)` fills `out` with pre-clamp sums; for the
+    GPU core it is `lambda out, **o: ctx.render_device(out.data_ptr(), **o)`."""
+    if scheme == "samples":
+        offset, count = shard_samples(spp_total, rank, world)
+        if count > 0:
+            stats = render_fn(out, spp=count, sample_offset=offset, spp_total=spp_total, **kw)
+        else:
+            out.zero_()
+            stats = None
+    elif scheme == "bands":
+        stats = render_fn(out, spp=spp_total, sample_offset=0, spp_total=spp_total, **shard_bands(rank, world, band), **kw)
+    else:
+        raise ValueError("scheme must be 'samples' or 'bands'")
+    if reduce and world > 1:
+        import torch.distributed as dist
+        dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+    return stats
