@@ -92,10 +92,10 @@ def main():
     def render_fn(o, **kw):
         return ctx.render_device(o.data_ptr(), **kw)
 
-    def step(profile=False, mode=None):
+    def step(profile=False, mode=None, reduce=True):
         # rank r renders samples [r*spp, (r+1)*spp) of every pixel, then RCCL reduce(sum) -> rank 0
-        return render_frame(render_fn, out, spp_total, rank, world, scheme="samples", mode=mode or args.mode,
-                            seed=13, profile=profile)
+        return render_frame(render_fn, out, spp_total, rank, world, scheme="samples", reduce=reduce,
+                            mode=mode or args.mode, seed=13, profile=profile)
 
     def fence():
         if world > 1:
@@ -121,7 +121,7 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: one more step with HIP events around every launch
         # on the render stream (same workload, same stream; not part of the timed region above)
-        ps = step(profile=True)
+        ps = step(profile=True, reduce=False)   # rank 0 only: no collective in here
         torch.cuda.synchronize()
         classes = {"extend": ps["ms_extend"], "shade": ps["ms_shade"], "shadow": ps["ms_shadow"]}
         dom = max(classes, key=classes.get)
@@ -150,7 +150,7 @@ def main():
         other_mode = "f32" if args.mode == "f64" else "f64"
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        step(mode=other_mode)
+        step(mode=other_mode, reduce=False)
         torch.cuda.synchronize()
         other_value = W * H * args.spp / (time.perf_counter() - t1) / 1e6 if world == 1 else None
 

@@ -73,6 +73,8 @@ typedef struct ptx_stats
     uint64_t segments;      /* closest-hit rays (one per bounce of every path)                   */
     uint64_t shadow_rays;   /* visibility tests issued                                           */
     uint64_t passes;        /* wavefront batches                                                 */
+    uint64_t wave_iterations; /* 64-lane iterations of the closest-hit kernel: segments /
+                               (64 * wave_iterations) is its active-lane fraction               */
     double ms_total;        /* device time of the call, HIP events on the context's stream       */
     double ms_extend, ms_shade, ms_shadow, ms_other; /* per-kernel-class device time (profiling
                                mode only, otherwise 0)                                           */
@@ -118,7 +120,9 @@ int ptx_context_create(int32_t hip_device, ptx_context **out);
 int ptx_context_set_stream(ptx_context *, void *hip_stream);
 void ptx_context_destroy(ptx_context *);
 /* Tunables: "brute_force_limit" (scenes with at most this many triangles use the all-triangles
- * loop instead of the BVH; default 64), "default_batch_paths".  Set before ptx_build_accel. */
+ * loop instead of the BVH; default 64), "default_batch_paths" (paths in flight per pass),
+ * "region_slots" (slots of one wave-private queue region, multiple of 64).  Set before
+ * ptx_build_accel. */
 int ptx_context_set_option(ptx_context *, const char *name, int64_t value);
 int ptx_build_accel(ptx_context *, const ptx_scene *);
 /* BVH statistics of the last build: n_nodes, n_leaves, max_depth, max_leaf_tris, brute_force flag */

@@ -161,8 +161,9 @@ template <class R> struct Context::Impl
     }
 
     // carve the state slab for `n` paths, `depth` bounces and `n_lights` deferred-NEE lights
-    void ensure_state(int64_t n, int depth, int n_lights_deferred)
+    void ensure_state(int64_t n, int depth, int n_lights_deferred, int region)
     {
+        st.region = region;
         if (n <= capacity && depth <= depth_cap && n_lights_deferred <= lights_cap)
             return;
         n = std::max(n, capacity);
@@ -176,7 +177,7 @@ template <class R> struct Context::Impl
             total += align(bytes);
             return off;
         };
-        size_t o_ray[2][6], o_pid[2], o_hitprim, o_hitpt[3], o_sd, o_sc, o_ps, o_ni, o_nm, o_nc, o_np, o_cnt, o_stats;
+        size_t o_ray[2][6], o_pid[2], o_hitprim, o_hitpt[3], o_sd, o_sc, o_ps, o_ni, o_nm, o_nc, o_np, o_cnt[2], o_ncnt, o_ws, o_stats;
         for (int q = 0; q < 2; q++)
         {
             for (int c = 0; c < 6; c++)
@@ -193,7 +194,12 @@ template <class R> struct Context::Impl
         o_nm = take(N * 4);
         o_nc = take(N * 3 * sizeof(R) * std::max(n_lights_deferred, 0));
         o_np = take(N * 3 * sizeof(R) * std::max(n_lights_deferred, 0));
-        o_cnt = take(sizeof(uint32_t) * (2 * depth + 2));
+        // regions are at least 64 slots, so N / 64 + 1 bounds their number for any region size
+        const size_t max_regions = N / 64 + 1;
+        o_cnt[0] = take(max_regions * 4);
+        o_cnt[1] = take(max_regions * 4);
+        o_ncnt = take(max_regions * 4);
+        o_ws = take(max_regions * 4 * sizeof(unsigned long long));
         o_stats = take(sizeof(unsigned long long) * 8);
         state_mem.alloc(total);
         char *base = static_cast<char *>(state_mem.p);
@@ -216,7 +222,10 @@ template <class R> struct Context::Impl
         st.nee_mask = reinterpret_cast<uint32_t *>(base + o_nm);
         st.nee_c = reinterpret_cast<R *>(base + o_nc);
         st.nee_p1 = reinterpret_cast<R *>(base + o_np);
-        st.counters = reinterpret_cast<uint32_t *>(base + o_cnt);
+        st.cnt[0] = reinterpret_cast<uint32_t *>(base + o_cnt[0]);
+        st.cnt[1] = reinterpret_cast<uint32_t *>(base + o_cnt[1]);
+        st.nee_cnt = reinterpret_cast<uint32_t *>(base + o_ncnt);
+        st.wave_stats = reinterpret_cast<unsigned long long *>(base + o_ws);
         st.stats = reinterpret_cast<unsigned long long *>(base + o_stats);
         st.N = n;
         capacity = n;
@@ -421,29 +430,33 @@ static void run_batch(const DScene<R> &S, const DCamera &cam, const DBatch &B, D
                       RenderTimers *tm)
 {
     const int depth = B.depth;
-    const dim3 block(BLOCK), grid(blocks_for(B.n_paths));
-    HIP_CHECK(hipMemsetAsync(st.counters, 0, sizeof(uint32_t) * (2 * depth + 2), s));
+    st.n_regions = static_cast<int>((B.n_paths + st.region - 1) / st.region);
+    const dim3 block(BLOCK);
+    const dim3 grid_paths(blocks_for(static_cast<int64_t>(st.n_regions) * st.region)); // one thread per slot
+    const dim3 grid_waves(blocks_for(static_cast<int64_t>(st.n_regions) * 64));        // one wave per region
     if (tm)
         tm->mark(s, RenderTimers::OTHER);
-    hipLaunchKernelGGL((k_raygen<R>), grid, block, 0, s, cam, B, st);
+    hipLaunchKernelGGL((k_raygen<R>), grid_paths, block, 0, s, cam, B, st);
     for (int b = 0; b < depth; b++)
     {
         if (tm)
             tm->mark(s, RenderTimers::EXTEND);
-        hipLaunchKernelGGL((k_extend<R, BRUTE>), grid, block, 0, s, S, st, b);
+        hipLaunchKernelGGL((k_extend<R, BRUTE>), grid_waves, block, 0, s, S, st, b);
         if (tm)
             tm->mark(s, RenderTimers::SHADE);
-        hipLaunchKernelGGL((k_shade<R>), grid, block, 0, s, S, B, st, b);
+        hipLaunchKernelGGL((k_shade<R>), grid_waves, block, 0, s, S, B, st, b);
         if (S.n_square > 0)
         {
             if (tm)
                 tm->mark(s, RenderTimers::SHADOW);
-            hipLaunchKernelGGL((k_shadow<R, BRUTE>), grid, block, 0, s, S, B, st, b);
+            hipLaunchKernelGGL((k_shadow<R, BRUTE>), grid_waves, block, 0, s, S, B, st, b);
         }
     }
     if (tm)
         tm->mark(s, RenderTimers::OTHER);
-    hipLaunchKernelGGL((k_resolve<R>), dim3(blocks_for(B.n_pix)), block, 0, s, S, B, st, sum, B.image_width);
+    hipLaunchKernelGGL((k_resolve<R>), dim3(blocks_for(B.n_paths)), block, 0, s, S, B, st);
+    hipLaunchKernelGGL((k_accumulate<R>), dim3(blocks_for(B.n_pix)), block, 0, s, B, st, sum);
+    hipLaunchKernelGGL((k_reduce_stats<R>), dim3(1), block, 0, s, B, st);
     if (tm)
         tm->mark(s, RenderTimers::END);
     HIP_CHECK(hipGetLastError());
@@ -530,7 +543,9 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     if (cap >= (int64_t(1) << 31))
         throw std::runtime_error("arg: batch_paths must stay below 2^31");
     const int deferred = sc.n_square_lights() > 0 ? static_cast<int>(sc.lights.size()) : 0;
-    im.ensure_state(cap, depth, deferred);
+    int region = region_slots > 0 ? region_slots : 512;
+    region = std::max(64, (region + 63) / 64 * 64);
+    im.ensure_state(cap, depth, deferred, region);
     HIP_CHECK(hipMemsetAsync(im.st.stats, 0, sizeof(unsigned long long) * 8, s));
 
     auto S = make_dscene<R>(sc, *geo_, im.tri_pre.p, im.mats.p, im.lights.p, brute_);
@@ -576,6 +591,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     stats.segments = h_stats[0];
     stats.shadow_rays = h_stats[1];
     stats.paths = h_stats[2];
+    stats.wave_iterations = h_stats[3];
     stats.passes = passes;
     stats.ms_total = ms;
     if (tm)

@@ -28,7 +28,7 @@ struct RenderOpts
 
 struct RenderStats
 {
-    uint64_t paths = 0, segments = 0, shadow_rays = 0, passes = 0;
+    uint64_t paths = 0, segments = 0, shadow_rays = 0, passes = 0, wave_iterations = 0;
     double ms_total = 0;
     double ms_class[4] = {0, 0, 0, 0}; // extend, shade, shadow, other
 };
@@ -74,7 +74,9 @@ public:
 
     // scenes up to this many triangles are intersected by the all-triangles loop
     int brute_force_limit = 64;
-    int64_t default_batch_paths = int64_t(1) << 22;
+    int64_t default_batch_paths = int64_t(1) << 23;
+    // slots per wave-private queue region (multiple of 64)
+    int region_slots = 512;
 
     struct Geometry;
     template <class R> struct Impl;

@@ -9,12 +9,18 @@
 //   k_extend ................. the RayCast call of the bounce loop, cPathTracer.cpp:596
 //   k_shade .................. bounce body: miss/emitter termination, shading normal, NEE set-up
 //                              (cBxDF::Sample_Li, src/tracing/cBxDF.cpp:16-52), next direction
-//                              (Sample_f), cPathTracer.cpp:598-673; appends the survivors to the
-//                              next queue (wave64 ballot + prefix sum, one atomic per workgroup)
+//                              (Sample_f), cPathTracer.cpp:598-673; packs the survivors to the
+//                              front of the wave's own queue region (wave64 ballot + popcount
+//                              prefix; no atomics, no barriers)
 //   k_shadow ................. the VisTest calls of Sample_Li and the in-order sum of the per-light
 //                              terms
-//   k_resolve ................ back-to-front combine with the per-bounce max-clamp and the
-//                              per-pixel average, cPathTracer.cpp:679-692
+//   k_resolve / k_accumulate . back-to-front combine with the per-bounce max-clamp, and the
+//                              per-pixel average in sample order, cPathTracer.cpp:679-692
+//
+// Queue layout: the N path slots of a batch are cut into regions of `region` consecutive slots,
+// one region per WAVE.  A wave only ever reads and writes its own region (of the ray queue, the hit
+// records, the deferred-NEE list), so dead paths are squeezed out with a ballot/popcount prefix
+// inside the wave and the per-region live count replaces any global queue tail.
 #pragma once
 #include "bvh.hpp"
 #include "device_math.hpp"
@@ -70,26 +76,31 @@ __device__ __forceinline__ int local_row_to_image_row(const DBatch &b, int lr)
     return b.region_row0 + (bi * b.row_stride + b.row_phase) * b.band + off;
 }
 
-// per-batch device state, SoA.  Arrays indexed by `i` are queue slots (dense, re-packed every
-// bounce); arrays indexed by `pid` are path slots (pid = sample_local * n_pix + pixel_local).
+// per-batch device state, SoA.  Arrays indexed by `slot` are queue slots (region-wise dense,
+// re-packed every bounce); arrays indexed by `pid` are path slots (pid = sample_local * n_pix +
+// pixel_local = the slot the path started in).
 template <class R> struct DState
 {
     R *ray_o[2][3], *ray_d[2][3]; // [2 queues][component][N]
     uint32_t *q_pid[2];           // [N]
-    int32_t *hit_prim;            // [N] ordered triangle index or -1
+    int32_t *hit_prim;            // [N] intersector-order triangle index or -1
     R *hit_pt[3];                 // [N]
     R *stack_d;                   // [depth][3][N] by pid
     R *stack_c;                   // [depth][3][N] by pid
     uint32_t *path_state;         // [N] by pid: (len << 16) | (tail material + 1)
     // deferred NEE (only when the scene has square lights).  The per-light terms stay at the
-    // queue slot i of the path; only the list of slots that need visibility tests is compacted.
-    uint32_t *nee_idx;            // [N] dense list of queue slots with pending tests
-    uint32_t *nee_mask;           // [N] by queue slot: bit l = light l needs a visibility test
-    R *nee_c;                     // [n_lights][3][N] by queue slot: per-light contribution
-    R *nee_p1;                    // [n_lights][3][N] by queue slot: light sample point
-    uint32_t *counters;           // [0..depth]: queue sizes per bounce; [depth+1 .. 2 depth+1): nee sizes
-    unsigned long long *stats;    // [0] segments [1] shadow rays [2] paths
+    // queue slot of the path; only the list of slots that need visibility tests is packed.
+    uint32_t *nee_idx;            // [N] region-wise dense list of slots with pending tests
+    uint32_t *nee_mask;           // [N] by slot: bit l = light l needs a visibility test
+    R *nee_c;                     // [n_lights][3][N] by slot: per-light contribution
+    R *nee_p1;                    // [n_lights][3][N] by slot: light sample point
+    uint32_t *cnt[2];             // [n_regions] live rays of each region, per queue buffer
+    uint32_t *nee_cnt;            // [n_regions] pending-NEE paths of each region
+    unsigned long long *wave_stats; // [n_regions][4] segments, shadow tests, wave iterations, spare
+    unsigned long long *stats;    // [8] totals (filled by k_reduce_stats)
     int64_t N;                    // capacity (paths per batch)
+    int region;                   // slots per wave region (multiple of 64)
+    int n_regions;                // regions in use by the current batch
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -349,11 +360,21 @@ __global__ void __launch_bounds__(BLOCK)
 }
 
 // ---------------------------------------------------------------------------------------------
-// wavefront kernels
+// wavefront kernels.  One wave per queue region; every loop below has a wave-uniform trip count.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int global_wave() { return int((blockIdx.x * BLOCK + threadIdx.x) >> 6); }
+__device__ __forceinline__ int lane_id() { return int(threadIdx.x & 63); }
+
 template <class R> __global__ void __launch_bounds__(BLOCK) k_raygen(DCamera cam, DBatch B, DState<R> st)
 {
     int64_t pid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (pid < (int64_t)st.n_regions * st.region && (pid % st.region) == 0)
+    {
+        const int64_t left = B.n_paths - pid;
+        const int g = int(pid / st.region);
+        st.cnt[0][g] = uint32_t(left < 0 ? 0 : (left < st.region ? left : st.region));
+        st.wave_stats[g * 4 + 0] = 0, st.wave_stats[g * 4 + 1] = 0, st.wave_stats[g * 4 + 2] = 0, st.wave_stats[g * 4 + 3] = 0;
+    }
     if (pid >= B.n_paths)
         return;
     int64_t pix = pid % B.n_pix;
@@ -365,233 +386,268 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_raygen(DCamera cam
     st.ray_d[0][0][pid] = d.x, st.ray_d[0][1][pid] = d.y, st.ray_d[0][2][pid] = d.z;
     st.q_pid[0][pid] = uint32_t(pid);
     st.path_state[pid] = uint32_t(B.depth) << 16; // default: survives every bounce, zero tail
-    if (pid == 0)
-    {
-        st.counters[0] = uint32_t(B.n_paths);
-        atomicAdd(&st.stats[2], (unsigned long long)B.n_paths);
-    }
 }
 
 template <class R, bool BRUTE> __global__ void __launch_bounds__(BLOCK) k_extend(DScene<R> S, DState<R> st, int bounce)
 {
     __shared__ int stk[BRUTE ? 1 : BVH_STACK * BLOCK];
-    const int q = bounce & 1;
-    const uint32_t count = st.counters[bounce];
-    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= count)
+    const int q = bounce & 1, g = global_wave(), lane = lane_id();
+    if (g >= st.n_regions)
         return;
-    V3<R> o = {st.ray_o[q][0][i], st.ray_o[q][1][i], st.ray_o[q][2][i]};
-    V3<R> d = {st.ray_d[q][0][i], st.ray_d[q][1][i], st.ray_d[q][2][i]};
-    V3<R> p = {R(0), R(0), R(0)};
-    int k = closest_hit<R, BRUTE>(S, o, d, p, stk + threadIdx.x);
-    st.hit_prim[i] = k;
-    st.hit_pt[0][i] = p.x, st.hit_pt[1][i] = p.y, st.hit_pt[2][i] = p.z;
-    if (i == 0)
-        atomicAdd(&st.stats[0], (unsigned long long)count);
-}
-
-// appends `alive` lanes to a queue: returns the slot (or -1).  wave64 ballot + popcount prefix,
-// wave totals combined in LDS, ONE global atomic per workgroup.  Must be called by all threads.
-__device__ __forceinline__ int64_t queue_append(bool alive, uint32_t *counter, uint32_t *lds /*[6]*/)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long m = __ballot(alive);
-    int prefix = __popcll(m & ((1ull << lane) - 1ull));
-    int total = __popcll(m);
-    if (lane == 0)
-        lds[wave] = total;
-    __syncthreads();
-    if (threadIdx.x == 0)
+    const int n = int(st.cnt[q][g]);
+    const int64_t base = (int64_t)g * st.region;
+    for (int j0 = 0; j0 < n; j0 += 64)
     {
-        uint32_t t0 = lds[0], t1 = lds[1], t2 = lds[2], t3 = lds[3];
-        uint32_t sum = t0 + t1 + t2 + t3;
-        uint32_t base = sum ? atomicAdd(counter, sum) : 0u;
-        lds[0] = base;
-        lds[1] = base + t0;
-        lds[2] = base + t0 + t1;
-        lds[3] = base + t0 + t1 + t2;
+        const int j = j0 + lane;
+        if (j < n)
+        {
+            const int64_t i = base + j;
+            V3<R> o = {st.ray_o[q][0][i], st.ray_o[q][1][i], st.ray_o[q][2][i]};
+            V3<R> d = {st.ray_d[q][0][i], st.ray_d[q][1][i], st.ray_d[q][2][i]};
+            V3<R> p = {R(0), R(0), R(0)};
+            int k = closest_hit<R, BRUTE>(S, o, d, p, stk + threadIdx.x);
+            st.hit_prim[i] = k;
+            st.hit_pt[0][i] = p.x, st.hit_pt[1][i] = p.y, st.hit_pt[2][i] = p.z;
+        }
     }
-    __syncthreads();
-    int64_t slot = alive ? int64_t(lds[wave]) + prefix : int64_t(-1);
-    __syncthreads(); // lds is reused by the next call
-    return slot;
+    if (lane == 0 && n > 0)
+    {
+        st.wave_stats[g * 4 + 0] += (unsigned long long)n;
+        st.wave_stats[g * 4 + 2] += (unsigned long long)((n + 63) >> 6);
+    }
 }
 
 template <class R> __global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S, DBatch B, DState<R> st, int bounce)
 {
-    __shared__ uint32_t lds[8];
-    const int q = bounce & 1, qn = q ^ 1;
-    const uint32_t count = st.counters[bounce];
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const bool active = i < count;
-    if ((int64_t)blockIdx.x * BLOCK >= count)
-        return; // whole workgroup idle
+    const int q = bounce & 1, qn = q ^ 1, g = global_wave(), lane = lane_id();
+    if (g >= st.n_regions)
+        return;
+    const int n = int(st.cnt[q][g]);
+    const int64_t base = (int64_t)g * st.region;
     const int64_t N = st.N;
+    int n_out = 0, n_nee = 0; // wave-uniform running counts of this region's two output lists
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    bool alive = false, defer = false;
-    uint32_t pid = 0, mask = 0;
-    V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
-
-    if (active)
+    for (int j0 = 0; j0 < n; j0 += 64)
     {
-        pid = st.q_pid[q][i];
-        const int k = st.hit_prim[i];
-        const int face = k < 0 ? -1 : S.tri_face[k];
-        const int mat_id = face < 0 ? -1 : S.mat_ids[face];
-        if (mat_id < 0)
-            st.path_state[pid] = uint32_t(bounce) << 16; // miss or no material: tail 0
-        else
+        const int j = j0 + lane;
+        const bool active = j < n;
+        const int64_t i = base + j;
+        bool alive = false, defer = false;
+        uint32_t pid = 0, mask = 0;
+        V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
+
+        if (active)
         {
-            const R *__restrict__ m = S.mats + (size_t)mat_id * MAT_STRIDE;
-            if (m[13] != R(0))
-                st.path_state[pid] = (uint32_t(bounce) << 16) | uint32_t(mat_id + 1); // emitter: tail Ka
+            pid = st.q_pid[q][i];
+            const int k = st.hit_prim[i];
+            const int face = k < 0 ? -1 : S.tri_face[k];
+            const int mat_id = face < 0 ? -1 : S.mat_ids[face];
+            if (mat_id < 0)
+                st.path_state[pid] = uint32_t(bounce) << 16; // miss or no material: tail 0
             else
             {
-                p = {st.hit_pt[0][i], st.hit_pt[1][i], st.hit_pt[2][i]};
-                V3<R> d = {st.ray_d[q][0][i], st.ray_d[q][1][i], st.ray_d[q][2][i]};
-                const float *__restrict__ vp = S.verts + (size_t)face * 9;
-                V3<R> a = {R(vp[0]), R(vp[1]), R(vp[2])}, b = {R(vp[3]), R(vp[4]), R(vp[5])}, c = {R(vp[6]), R(vp[7]), R(vp[8])};
-                V3<R> n;
-                if (S.enable_bary)
-                {
-                    const float *__restrict__ np = S.normals + (size_t)face * 9;
-                    V3<R> w = barycentric(p, a, b, c);
-                    V3<R> acc = {R(0), R(0), R(0)};
-                    acc = acc + w.x * V3<R>{R(np[0]), R(np[1]), R(np[2])};
-                    acc = acc + w.y * V3<R>{R(np[3]), R(np[4]), R(np[5])};
-                    acc = acc + w.z * V3<R>{R(np[6]), R(np[7]), R(np[8])};
-                    n = normalized(acc);
-                }
+                const R *__restrict__ m = S.mats + (size_t)mat_id * MAT_STRIDE;
+                if (m[13] != R(0))
+                    st.path_state[pid] = (uint32_t(bounce) << 16) | uint32_t(mat_id + 1); // emitter: tail Ka
                 else
-                    n = normalized(cross(b - a, c - b));
-
-                // which pixel / sample this path belongs to (RNG key)
-                const int64_t pix = int64_t(pid) % B.n_pix;
-                const int s_local = int(int64_t(pid) / B.n_pix);
-                const int lr = B.row0 + int(pix / B.n_cols), col = B.col0 + int(pix % B.n_cols);
-                const uint32_t pixel = uint32_t(local_row_to_image_row(B, lr)) * uint32_t(B.image_width) + uint32_t(col);
-                const uint32_t sample = uint32_t(B.sample0 + s_local);
-                const uint64_t key = rng_pixel_key(B.seed, pixel);
-                const V3<R> wo = -d;
-
-                // NEE over all lights, in order
-                V3<R> direct = {R(0), R(0), R(0)};
-                for (int l = 0; l < S.n_lights; l++)
                 {
-                    const R *__restrict__ L = S.lights + (size_t)l * LIGHT_STRIDE;
-                    V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
-                    R pdf;
-                    const R x1 = rng_draw<R>(key, sample, bounce, 4 * l + 0);
-                    const R x2 = rng_draw<R>(key, sample, bounce, 4 * l + 1);
-                    const bool square = L[0] == R(0);
-                    if (square)
-                        pdf = square_light_sample(L, p, x1, x2, ro, rd);
+                    p = {st.hit_pt[0][i], st.hit_pt[1][i], st.hit_pt[2][i]};
+                    V3<R> d = {st.ray_d[q][0][i], st.ray_d[q][1][i], st.ray_d[q][2][i]};
+                    const float *__restrict__ vp = S.verts + (size_t)face * 9;
+                    V3<R> a = {R(vp[0]), R(vp[1]), R(vp[2])}, b = {R(vp[3]), R(vp[4]), R(vp[5])}, c = {R(vp[6]), R(vp[7]), R(vp[8])};
+                    V3<R> nrm;
+                    if (S.enable_bary)
+                    {
+                        const float *__restrict__ np = S.normals + (size_t)face * 9;
+                        V3<R> w = barycentric(p, a, b, c);
+                        V3<R> acc = {R(0), R(0), R(0)};
+                        acc = acc + w.x * V3<R>{R(np[0]), R(np[1]), R(np[2])};
+                        acc = acc + w.y * V3<R>{R(np[3]), R(np[4]), R(np[5])};
+                        acc = acc + w.z * V3<R>{R(np[6]), R(np[7]), R(np[8])};
+                        nrm = normalized(acc);
+                    }
                     else
-                        pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bounce, 4 * l + 2), ro, rd);
-                    V3<R> term = {R(0), R(0), R(0)};
-                    bool valid = false;
-                    if (!(pdf < R(1e-10)))
+                        nrm = normalized(cross(b - a, c - b));
+
+                    // which pixel / sample this path belongs to (RNG key)
+                    const int64_t pix = int64_t(pid) % B.n_pix;
+                    const int s_local = int(int64_t(pid) / B.n_pix);
+                    const int lr = B.row0 + int(pix / B.n_cols), col = B.col0 + int(pix % B.n_cols);
+                    const uint32_t pixel = uint32_t(local_row_to_image_row(B, lr)) * uint32_t(B.image_width) + uint32_t(col);
+                    const uint32_t sample = uint32_t(B.sample0 + s_local);
+                    const uint64_t key = rng_pixel_key(B.seed, pixel);
+                    const V3<R> wo = -d;
+
+                    // NEE over all lights, in order
+                    V3<R> direct = {R(0), R(0), R(0)};
+                    for (int l = 0; l < S.n_lights; l++)
                     {
-                        R cn = dot(n, -rd);
-                        if (!(cn < R(0)))
+                        const R *__restrict__ L = S.lights + (size_t)l * LIGHT_STRIDE;
+                        V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
+                        R pdf;
+                        const R x1 = rng_draw<R>(key, sample, bounce, 4 * l + 0);
+                        const R x2 = rng_draw<R>(key, sample, bounce, 4 * l + 1);
+                        const bool square = L[0] == R(0);
+                        if (square)
+                            pdf = square_light_sample(L, p, x1, x2, ro, rd);
+                        else
+                            pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bounce, 4 * l + 2), ro, rd);
+                        V3<R> term = {R(0), R(0), R(0)};
+                        bool valid = false;
+                        if (!(pdf < R(1e-10)))
                         {
-                            V3<R> f = bxdf_eval(m, rd, wo, n);
-                            term = {(L[1] * cn / pdf) * f.x, (L[2] * cn / pdf) * f.y, (L[3] * cn / pdf) * f.z};
-                            valid = true;
+                            R cn = dot(nrm, -rd);
+                            if (!(cn < R(0)))
+                            {
+                                V3<R> f = bxdf_eval(m, rd, wo, nrm);
+                                term = {(L[1] * cn / pdf) * f.x, (L[2] * cn / pdf) * f.y, (L[3] * cn / pdf) * f.z};
+                                valid = true;
+                            }
                         }
+                        if (S.n_square > 0)
+                        {
+                            R *cdst = st.nee_c + (size_t)l * 3 * N, *pdst = st.nee_p1 + (size_t)l * 3 * N;
+                            cdst[i] = term.x, cdst[N + i] = term.y, cdst[2 * N + i] = term.z;
+                            pdst[i] = ro.x, pdst[N + i] = ro.y, pdst[2 * N + i] = ro.z;
+                        }
+                        if (valid && square)
+                            mask |= 1u << l;
+                        direct = direct + term;
                     }
-                    if (S.n_square > 0)
+                    defer = mask != 0;
+                    if (!defer)
                     {
-                        R *cdst = st.nee_c + (size_t)l * 3 * N, *pdst = st.nee_p1 + (size_t)l * 3 * N;
-                        cdst[i] = term.x, cdst[N + i] = term.y, cdst[2 * N + i] = term.z;
-                        pdst[i] = ro.x, pdst[N + i] = ro.y, pdst[2 * N + i] = ro.z;
+                        R *D = st.stack_d + (size_t)bounce * 3 * N;
+                        D[pid] = direct.x, D[N + pid] = direct.y, D[2 * N + pid] = direct.z;
                     }
-                    if (valid && square)
-                        mask |= 1u << l;
-                    direct = direct + term;
+                    // next direction
+                    V3<R> coef = {R(0), R(0), R(0)};
+                    if (S.enable_indirect)
+                    {
+                        const R x1 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 0);
+                        const R x2 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 1);
+                        bxdf_sample(m, nrm, wo, x1, x2, wi, coef);
+                        alive = bounce + 1 < B.depth;
+                    }
+                    else
+                        st.path_state[pid] = uint32_t(bounce + 1) << 16;
+                    R *C = st.stack_c + (size_t)bounce * 3 * N;
+                    C[pid] = coef.x, C[N + pid] = coef.y, C[2 * N + pid] = coef.z;
                 }
-                defer = mask != 0;
-                if (!defer)
-                {
-                    R *D = st.stack_d + (size_t)bounce * 3 * N;
-                    D[pid] = direct.x, D[N + pid] = direct.y, D[2 * N + pid] = direct.z;
-                }
-                // next direction
-                V3<R> coef = {R(0), R(0), R(0)};
-                if (S.enable_indirect)
-                {
-                    const R x1 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 0);
-                    const R x2 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 1);
-                    bxdf_sample(m, n, wo, x1, x2, wi, coef);
-                    alive = bounce + 1 < B.depth;
-                }
-                else
-                    st.path_state[pid] = uint32_t(bounce + 1) << 16;
-                R *C = st.stack_c + (size_t)bounce * 3 * N;
-                C[pid] = coef.x, C[N + pid] = coef.y, C[2 * N + pid] = coef.z;
             }
         }
-    }
 
-    // survivors -> next queue
-    int64_t slot = queue_append(alive, &st.counters[bounce + 1], lds);
-    if (alive)
-    {
-        st.ray_o[qn][0][slot] = p.x, st.ray_o[qn][1][slot] = p.y, st.ray_o[qn][2][slot] = p.z;
-        st.ray_d[qn][0][slot] = wi.x, st.ray_d[qn][1][slot] = wi.y, st.ray_d[qn][2][slot] = wi.z;
-        st.q_pid[qn][slot] = pid;
-    }
-    // paths with NEE terms that need a visibility test -> shadow list
-    if (S.n_square > 0)
-    {
-        int64_t ns = queue_append(defer, &st.counters[B.depth + 1 + bounce], lds);
-        if (defer)
+        // survivors -> front of this region in the other queue buffer
+        const unsigned long long am = __ballot(alive);
+        if (alive)
         {
-            st.nee_idx[ns] = uint32_t(i);
-            st.nee_mask[i] = mask;
+            const int64_t slot = base + n_out + __popcll(am & lt_mask);
+            st.ray_o[qn][0][slot] = p.x, st.ray_o[qn][1][slot] = p.y, st.ray_o[qn][2][slot] = p.z;
+            st.ray_d[qn][0][slot] = wi.x, st.ray_d[qn][1][slot] = wi.y, st.ray_d[qn][2][slot] = wi.z;
+            st.q_pid[qn][slot] = pid;
         }
+        n_out += __popcll(am);
+        // paths with NEE terms that need a visibility test -> this region's shadow list
+        if (S.n_square > 0)
+        {
+            const unsigned long long dm = __ballot(defer);
+            if (defer)
+            {
+                st.nee_idx[base + n_nee + __popcll(dm & lt_mask)] = uint32_t(j);
+                st.nee_mask[i] = mask;
+            }
+            n_nee += __popcll(dm);
+        }
+    }
+    if (lane == 0)
+    {
+        st.cnt[qn][g] = uint32_t(n_out);
+        st.nee_cnt[g] = uint32_t(n_nee);
     }
 }
 
 template <class R, bool BRUTE> __global__ void __launch_bounds__(BLOCK) k_shadow(DScene<R> S, DBatch B, DState<R> st, int bounce)
 {
     __shared__ int stk[BRUTE ? 1 : BVH_STACK * BLOCK];
-    const uint32_t count = st.counters[B.depth + 1 + bounce];
-    const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (j >= count)
+    const int q = bounce & 1, g = global_wave(), lane = lane_id();
+    if (g >= st.n_regions)
         return;
+    const int n = int(st.nee_cnt[g]);
+    const int64_t base = (int64_t)g * st.region;
     const int64_t N = st.N;
-    const uint32_t i = st.nee_idx[j];
-    const uint32_t pid = st.q_pid[bounce & 1][i], mask = st.nee_mask[i];
-    const V3<R> p2 = {st.hit_pt[0][i], st.hit_pt[1][i], st.hit_pt[2][i]};
-    V3<R> direct = {R(0), R(0), R(0)};
     const int nl = S.n_lights;
     unsigned long long tests = 0;
-    for (int l = 0; l < nl; l++)
+    for (int j0 = 0; j0 < n; j0 += 64)
     {
-        const R *csrc = st.nee_c + (size_t)l * 3 * N;
-        V3<R> term = {csrc[i], csrc[N + i], csrc[2 * N + i]};
-        if (mask & (1u << l))
+        const int j = j0 + lane;
+        if (j < n)
         {
-            const R *psrc = st.nee_p1 + (size_t)l * 3 * N;
-            V3<R> p1 = {psrc[i], psrc[N + i], psrc[2 * N + i]};
-            tests++;
-            if (!visible<R, BRUTE>(S, p1, p2, stk + threadIdx.x))
-                continue;
+            const int64_t i = base + st.nee_idx[base + j];
+            const uint32_t pid = st.q_pid[q][i], mask = st.nee_mask[i];
+            const V3<R> p2 = {st.hit_pt[0][i], st.hit_pt[1][i], st.hit_pt[2][i]};
+            V3<R> direct = {R(0), R(0), R(0)};
+            for (int l = 0; l < nl; l++)
+            {
+                const R *csrc = st.nee_c + (size_t)l * 3 * N;
+                V3<R> term = {csrc[i], csrc[N + i], csrc[2 * N + i]};
+                if (mask & (1u << l))
+                {
+                    const R *psrc = st.nee_p1 + (size_t)l * 3 * N;
+                    V3<R> p1 = {psrc[i], psrc[N + i], psrc[2 * N + i]};
+                    tests++;
+                    if (!visible<R, BRUTE>(S, p1, p2, stk + threadIdx.x))
+                        continue;
+                }
+                direct = direct + term;
+            }
+            R *D = st.stack_d + (size_t)bounce * 3 * N;
+            D[pid] = direct.x, D[N + pid] = direct.y, D[2 * N + pid] = direct.z;
         }
-        direct = direct + term;
     }
-    R *D = st.stack_d + (size_t)bounce * 3 * N;
-    D[pid] = direct.x, D[N + pid] = direct.y, D[2 * N + pid] = direct.z;
-    // one atomic per wave for the shadow-ray statistic
     for (int off = 32; off > 0; off >>= 1)
         tests += __shfl_down(tests, off, 64);
-    if ((threadIdx.x & 63) == 0 && tests)
-        atomicAdd(&st.stats[1], tests);
+    if (lane == 0 && tests)
+        st.wave_stats[g * 4 + 1] += tests; // the wave owns its row: plain read-modify-write
 }
 
-// one thread per pixel of the batch: resolves its samples in order and continues the running sum
-template <class R> __global__ void __launch_bounds__(BLOCK) k_resolve(DScene<R> S, DBatch B, DState<R> st, double *__restrict__ sum, int image_width)
+// one thread per path: folds its (direct, coefficient) stack back to front with the per-bounce
+// max-clamp; the per-sample result overwrites stack_d[0][.][pid]
+template <class R> __global__ void __launch_bounds__(BLOCK) k_resolve(DScene<R> S, DBatch B, DState<R> st)
+{
+    const int64_t pid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (pid >= B.n_paths)
+        return;
+    const int64_t N = st.N;
+    const uint32_t ps = st.path_state[pid];
+    const int len = int(ps >> 16), tm = int(ps & 0xffff);
+    R fr = R(0), fg = R(0), fb = R(0);
+    if (tm)
+    {
+        const R *m = S.mats + (size_t)(tm - 1) * MAT_STRIDE;
+        fr = m[0], fg = m[1], fb = m[2];
+    }
+    for (int i = len - 1; i >= 0; i--)
+    {
+        const R *D = st.stack_d + (size_t)i * 3 * N, *C = st.stack_c + (size_t)i * 3 * N;
+        fr = D[pid] + C[pid] * fr;
+        fg = D[N + pid] + C[N + pid] * fg;
+        fb = D[2 * N + pid] + C[2 * N + pid] * fb;
+        R mx = fr;
+        if (fg > mx)
+            mx = fg;
+        if (fb > mx)
+            mx = fb;
+        if (R(0) > mx)
+            mx = R(0);
+        if (mx > R(1))
+            fr /= mx, fg /= mx, fb /= mx;
+    }
+    st.stack_d[pid] = fr, st.stack_d[N + pid] = fg, st.stack_d[2 * N + pid] = fb;
+}
+
+// one thread per pixel of the batch: continues the running per-pixel sum in sample order
+template <class R> __global__ void __launch_bounds__(BLOCK) k_accumulate(DBatch B, DState<R> st, double *__restrict__ sum)
 {
     const int64_t pix = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (pix >= B.n_pix)
@@ -599,40 +655,43 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_resolve(DScene<R> 
     const int64_t N = st.N;
     const int lr = B.row0 + int(pix / B.n_cols), col = B.col0 + int(pix % B.n_cols);
     const int row = local_row_to_image_row(B, lr);
-    double *dst = sum + ((int64_t)row * image_width + col) * 3;
+    double *dst = sum + ((int64_t)row * B.image_width + col) * 3;
     double cr = dst[0], cg = dst[1], cb = dst[2];
     for (int s = 0; s < B.n_samples; s++)
     {
         const int64_t pid = (int64_t)s * B.n_pix + pix;
-        const uint32_t ps = st.path_state[pid];
-        const int len = int(ps >> 16), tm = int(ps & 0xffff);
-        R fr = R(0), fg = R(0), fb = R(0);
-        if (tm)
-        {
-            const R *m = S.mats + (size_t)(tm - 1) * MAT_STRIDE;
-            fr = m[0], fg = m[1], fb = m[2];
-        }
-        for (int i = len - 1; i >= 0; i--)
-        {
-            const R *D = st.stack_d + (size_t)i * 3 * N, *C = st.stack_c + (size_t)i * 3 * N;
-            fr = D[pid] + C[pid] * fr;
-            fg = D[N + pid] + C[N + pid] * fg;
-            fb = D[2 * N + pid] + C[2 * N + pid] * fb;
-            R mx = fr;
-            if (fg > mx)
-                mx = fg;
-            if (fb > mx)
-                mx = fb;
-            if (R(0) > mx)
-                mx = R(0);
-            if (mx > R(1))
-                fr /= mx, fg /= mx, fb /= mx;
-        }
-        cr += double(fr) / B.spp_total;
-        cg += double(fg) / B.spp_total;
-        cb += double(fb) / B.spp_total;
+        cr += double(st.stack_d[pid]) / B.spp_total;
+        cg += double(st.stack_d[N + pid]) / B.spp_total;
+        cb += double(st.stack_d[2 * N + pid]) / B.spp_total;
     }
     dst[0] = cr, dst[1] = cg, dst[2] = cb;
+}
+
+// sums the per-region statistics of a batch into the totals (single workgroup, no atomics)
+template <class R> __global__ void __launch_bounds__(BLOCK) k_reduce_stats(DBatch B, DState<R> st)
+{
+    __shared__ unsigned long long part[4][BLOCK];
+    unsigned long long a[4] = {0, 0, 0, 0};
+    for (int g = threadIdx.x; g < st.n_regions; g += BLOCK)
+        for (int c = 0; c < 4; c++)
+            a[c] += st.wave_stats[g * 4 + c];
+    for (int c = 0; c < 4; c++)
+        part[c][threadIdx.x] = a[c];
+    __syncthreads();
+    for (int w = BLOCK / 2; w > 0; w >>= 1)
+    {
+        if (int(threadIdx.x) < w)
+            for (int c = 0; c < 4; c++)
+                part[c][threadIdx.x] += part[c][threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        st.stats[0] += part[0][0]; // segments
+        st.stats[1] += part[1][0]; // shadow tests
+        st.stats[2] += (unsigned long long)B.n_paths;
+        st.stats[3] += part[2][0]; // wave iterations of k_extend (64 lanes each)
+    }
 }
 
 } // namespace ptx
