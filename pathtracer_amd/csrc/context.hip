@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <stdexcept>
 
 namespace ptx
@@ -66,7 +67,7 @@ inline unsigned blocks_for(int64_t n) { return static_cast<unsigned>(std::max<in
 // per-precision device tables + wavefront state
 template <class R> struct Context::Impl
 {
-    DeviceBuffer tri_pre, mats, lights;
+    DeviceBuffer tri_pre, tri_pf, mats, lights, face_nrm;
     DeviceBuffer state_mem; // one slab carved into the DState arrays
     DState<R> st;
     int64_t capacity = 0;
@@ -99,6 +100,35 @@ template <class R> struct Context::Impl
             o[11] = t0 - t1;
         }
         upload(tri_pre, pre, s);
+
+        // f32 prefilter records of the two-phase all-triangles intersector (see kernels.hpp)
+        std::vector<float> pf(static_cast<size_t>(std::max(F, 1)) * PF_STRIDE, 0.f);
+        if (brute)
+        {
+            const double K = 128.0 * std::ldexp(1.0, -24);
+            for (int k = 0; k < F; k++)
+            {
+                const float *v = &sc.verts[static_cast<size_t>(k) * 9];
+                float *o = &pf[static_cast<size_t>(k) * PF_STRIDE];
+                double e1m = 0, e2m = 0, p1m = 0;
+                for (int c = 0; c < 3; c++)
+                {
+                    double e1 = double(v[3 + c]) - double(v[c]), e2 = double(v[6 + c]) - double(v[c]);
+                    o[c] = v[c];
+                    o[3 + c] = static_cast<float>(e1);
+                    o[6 + c] = static_cast<float>(e2);
+                    e1m = std::max(e1m, std::fabs(e1)), e2m = std::max(e2m, std::fabs(e2));
+                    p1m = std::max(p1m, std::fabs(double(v[c])));
+                }
+                // bounds rounded up when narrowed to float
+                auto up = [](double x) { return std::nextafter(static_cast<float>(x), std::numeric_limits<float>::infinity()); };
+                o[9] = up(K * e2m), o[10] = up(K * e1m), o[11] = up(K * e1m * e2m), o[12] = up(K * e1m * e2m);
+                o[13] = up(p1m);
+                o[14] = up(1.001 * (double(o[9]) + double(o[10])));
+                o[15] = up(1.001 * double(o[12]));
+            }
+        }
+        upload(tri_pf, pf, s);
 
         std::vector<R> m(static_cast<size_t>(std::max<size_t>(sc.mats.size(), 1)) * MAT_STRIDE, R(0));
         for (size_t i = 0; i < sc.mats.size(); i++)
@@ -157,6 +187,46 @@ template <class R> struct Context::Impl
             }
         }
         upload(lights, L, s);
+
+        // per-face shading normal where it does not depend on the hit point: flat faces (three equal
+        // vertex normals) when barycentric normals are on, the geometric normal when they are off
+        // (or when the OBJ carries no normals at all)
+        std::vector<R> fn(static_cast<size_t>(std::max(F, 1)) * 4, R(0));
+        const bool bary = sc.enable_bary_normal && sc.has_normals;
+        for (int f = 0; f < F; f++)
+        {
+            const float *v = &sc.verts[static_cast<size_t>(f) * 9];
+            const float *n = &sc.normals[static_cast<size_t>(f) * 9];
+            double g[3];
+            bool use = false;
+            if (!bary)
+            {
+                double e1[3], e2[3];
+                for (int c = 0; c < 3; c++)
+                {
+                    e1[c] = double(v[3 + c]) - double(v[c]);
+                    e2[c] = double(v[6 + c]) - double(v[3 + c]);
+                }
+                g[0] = e1[1] * e2[2] - e1[2] * e2[1];
+                g[1] = e1[2] * e2[0] - e1[0] * e2[2];
+                g[2] = e1[0] * e2[1] - e1[1] * e2[0];
+                use = true;
+            }
+            else if (std::memcmp(n, n + 3, 12) == 0 && std::memcmp(n, n + 6, 12) == 0 && !std::isnan(n[0]) &&
+                     !std::isnan(n[1]) && !std::isnan(n[2]))
+            {
+                g[0] = n[0], g[1] = n[1], g[2] = n[2];
+                use = true;
+            }
+            if (use)
+            {
+                double z = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+                double k = z > 0 ? 1.0 / std::sqrt(z) : 1.0;
+                R *o = &fn[static_cast<size_t>(f) * 4];
+                o[0] = R(g[0] * k), o[1] = R(g[1] * k), o[2] = R(g[2] * k), o[3] = R(1);
+            }
+        }
+        upload(face_nrm, fn, s);
         ready = true;
     }
 
@@ -177,12 +247,13 @@ template <class R> struct Context::Impl
             total += align(bytes);
             return off;
         };
-        size_t o_ray[2][6], o_pid[2], o_hitprim, o_hitpt[3], o_sd, o_sc, o_ps, o_ni, o_nm, o_nc, o_np, o_cnt[2], o_ncnt, o_ws, o_stats;
+        size_t o_ray[2][6], o_pid[2], o_prim[2], o_hitprim, o_hitpt[3], o_sd, o_sc, o_ps, o_ni, o_nm, o_nc, o_np, o_cnt[2], o_ncnt, o_ws, o_stats;
         for (int q = 0; q < 2; q++)
         {
             for (int c = 0; c < 6; c++)
                 o_ray[q][c] = take(N * sizeof(R));
             o_pid[q] = take(N * 4);
+            o_prim[q] = take(N * 4);
         }
         o_hitprim = take(N * 4);
         for (int c = 0; c < 3; c++)
@@ -211,6 +282,7 @@ template <class R> struct Context::Impl
                 st.ray_d[q][c] = reinterpret_cast<R *>(base + o_ray[q][3 + c]);
             }
             st.q_pid[q] = reinterpret_cast<uint32_t *>(base + o_pid[q]);
+            st.q_prim[q] = reinterpret_cast<int32_t *>(base + o_prim[q]);
         }
         st.hit_prim = reinterpret_cast<int32_t *>(base + o_hitprim);
         for (int c = 0; c < 3; c++)
@@ -268,7 +340,7 @@ void Context::build_accel(const Scene &sc)
     HIP_CHECK(hipSetDevice(device_));
     hipStream_t s = static_cast<hipStream_t>(stream_);
     scene_ = sc; // host copy (camera, tracer settings)
-    brute_ = sc.n_tris() <= brute_force_limit;
+    brute_ = sc.n_tris() <= std::min(brute_force_limit, BRUTE_MAX_TRIS);
     bvh_ = Bvh();
     build_bvh(sc.verts.data(), sc.n_tris(), bvh_, 4);
     if (!brute_ && bvh_.max_depth + 2 > BVH_STACK)
@@ -295,8 +367,8 @@ void Context::build_accel(const Scene &sc)
     have_scene_ = true;
 }
 
-template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::Geometry &g, const void *tri_pre, const void *mats,
-                                                 const void *lights, bool brute)
+template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::Geometry &g, const void *tri_pre, const void *tri_pf,
+                                                 const void *mats, const void *lights, const void *face_nrm, bool brute)
 {
     DScene<R> S;
     S.n_tris = sc.n_tris();
@@ -308,12 +380,14 @@ template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::
     S.enable_bary = sc.enable_bary_normal && sc.has_normals;
     S.pad0 = 0;
     S.tri_pre = static_cast<const R *>(tri_pre);
+    S.tri_pf = static_cast<const float *>(tri_pf);
     S.tri_face = static_cast<const int32_t *>(g.tri_face.p);
     S.verts = static_cast<const float *>(g.verts.p);
     S.normals = static_cast<const float *>(g.normals.p);
     S.mat_ids = static_cast<const int32_t *>(g.mat_ids.p);
     S.mats = static_cast<const R *>(mats);
     S.lights = static_cast<const R *>(lights);
+    S.face_nrm = static_cast<const R *>(face_nrm);
     S.nodes = static_cast<const BvhNode *>(g.nodes.p);
     return S;
 }
@@ -377,7 +451,7 @@ void Context::raycast(const double *ro, const double *rd, int64_t n, int32_t *id
     double *pp = pts ? static_cast<double *>(d_pts.p) : nullptr;
     if (mode == PTX_MODE_F64_)
     {
-        auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->mats.p, f64_->lights.p, brute_);
+        auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->tri_pf.p, f64_->mats.p, f64_->lights.p, f64_->face_nrm.p, brute_);
         if (brute_)
             hipLaunchKernelGGL((k_raycast<double, true>), grid, block, 0, s, S, cam, int(from_camera), po, pd, n, pi, pp);
         else
@@ -385,7 +459,7 @@ void Context::raycast(const double *ro, const double *rd, int64_t n, int32_t *id
     }
     else
     {
-        auto S = make_dscene<float>(scene_, *geo_, f32_->tri_pre.p, f32_->mats.p, f32_->lights.p, brute_);
+        auto S = make_dscene<float>(scene_, *geo_, f32_->tri_pre.p, f32_->tri_pf.p, f32_->mats.p, f32_->lights.p, f32_->face_nrm.p, brute_);
         if (brute_)
             hipLaunchKernelGGL((k_raycast<float, true>), grid, block, 0, s, S, cam, int(from_camera), po, pd, n, pi, pp);
         else
@@ -409,7 +483,7 @@ void Context::vistest(const double *p1, const double *p2, int64_t n, int32_t *vi
     d1.alloc(n * 24), d2.alloc(n * 24), dv.alloc(n * 4);
     HIP_CHECK(hipMemcpyAsync(d1.p, p1, n * 24, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemcpyAsync(d2.p, p2, n * 24, hipMemcpyHostToDevice, s));
-    auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->mats.p, f64_->lights.p, brute_);
+    auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->tri_pf.p, f64_->mats.p, f64_->lights.p, f64_->face_nrm.p, brute_);
     const dim3 grid(blocks_for(n)), block(BLOCK);
     if (brute_)
         hipLaunchKernelGGL((k_vistest<double, true>), grid, block, 0, s, S, static_cast<const double *>(d1.p),
@@ -548,7 +622,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     im.ensure_state(cap, depth, deferred, region);
     HIP_CHECK(hipMemsetAsync(im.st.stats, 0, sizeof(unsigned long long) * 8, s));
 
-    auto S = make_dscene<R>(sc, *geo_, im.tri_pre.p, im.mats.p, im.lights.p, brute_);
+    auto S = make_dscene<R>(sc, *geo_, im.tri_pre.p, im.tri_pf.p, im.mats.p, im.lights.p, im.face_nrm.p, brute_);
     DCamera cam = make_camera(sc);
     RenderTimers *tm = o.profile ? &timers_ : nullptr;
 

@@ -49,6 +49,21 @@ template <class R> __device__ __forceinline__ V3<R> normalized(V3<R> a)
 }
 template <class R> __device__ __forceinline__ bool has_nan(V3<R> a) { return isnan(a.x) || isnan(a.y) || isnan(a.z); }
 
+// Shading-side helpers.  The intersector keeps the reference's exact operation order (its accept /
+// reject decisions and distances are compared bit for bit with the CPU restatement); the shading
+// math below uses algebraically identical but cheaper forms (reciprocal square roots, no inverse
+// trigonometry), which moves results by a few ulps only.
+__device__ __forceinline__ double rsqrt_(double x) { return rsqrt(x); }
+__device__ __forceinline__ float rsqrt_(float x) { return rsqrtf(x); }
+__device__ __forceinline__ void sincospi_(double x, double &s, double &c) { sincospi(x, &s, &c); }
+__device__ __forceinline__ void sincospi_(float x, float &s, float &c) { sincospif(x, &s, &c); }
+template <class R> __device__ __forceinline__ V3<R> fast_normalized(V3<R> a)
+{
+    R z = a.x * a.x + a.y * a.y + a.z * a.z;
+    R k = z > R(0) ? rsqrt_(z) : R(1);
+    return {a.x * k, a.y * k, a.z * k};
+}
+
 template <class R> struct Consts;
 template <> struct Consts<double>
 {
@@ -160,7 +175,9 @@ template <class R> __device__ __forceinline__ V3<R> solve3(const R *m, V3<R> p)
     return {i0 * p.x + i1 * p.y + i2 * p.z, i3 * p.x + i4 * p.y + i5 * p.z, i6 * p.x + i7 * p.y + i8 * p.z};
 }
 
-// barycentric weights of p w.r.t. (a,b,c): [a b c]^-1 p with all-zero rows regularised, normalised
+// barycentric weights of p w.r.t. (a,b,c): [a b c]^-1 p with all-zero rows regularised.  The
+// reference normalises the weight vector; the caller normalises the interpolated normal anyway, so
+// that positive scale is dropped here.
 template <class R> __device__ __forceinline__ V3<R> barycentric(V3<R> p, V3<R> a, V3<R> b, V3<R> c)
 {
     R m[9] = {a.x, b.x, c.x, a.y, b.y, c.y, a.z, b.z, c.z};
@@ -168,52 +185,41 @@ template <class R> __device__ __forceinline__ V3<R> barycentric(V3<R> p, V3<R> a
 #pragma unroll
     for (int i = 0; i < 3; i++)
     {
-        R rn = sqrt(m[i * 3] * m[i * 3] + m[i * 3 + 1] * m[i * 3 + 1] + m[i * 3 + 2] * m[i * 3 + 2]);
-        if (rn < R(1e-10))
+        R rn2 = m[i * 3] * m[i * 3] + m[i * 3 + 1] * m[i * 3 + 1] + m[i * 3 + 2] * m[i * 3 + 2];
+        if (rn2 < R(1e-20))
         {
             m[i * 3] += R(1e-6), m[i * 3 + 1] += R(1e-6), m[i * 3 + 2] += R(1e-6);
             pv[i] += R(1e-6);
         }
     }
-    return normalized(solve3(m, V3<R>{pv[0], pv[1], pv[2]}));
+    return solve3(m, V3<R>{pv[0], pv[1], pv[2]});
 }
 
-// direction about `n`: elevation theta = acos(1 - xi1), azimuth 2 pi xi2, rotated from +Y to n by
-// the quaternion of axis normalize(Y x (n - Y)) and angle acos(n.y)
+// direction about `n`.  The reference draws an elevation theta = acos(1 - xi1) and an azimuth
+// phi = 2 pi xi2, builds (cos theta cos phi, sin theta, -cos theta sin phi) about +Y and rotates +Y
+// onto n with the quaternion of axis Y x (n - Y) and angle acos(n.y).  Same map here without inverse
+// trigonometry: cos theta = 1 - xi1, sin theta = sqrt(xi1 (2 - xi1)), and the rotation in Rodrigues
+// form with cos = n.y, sin = |(n.x, n.z)|, axis (n.z, 0, -n.x) / sin.
 template <class R> __device__ __forceinline__ V3<R> sample_hemisphere(V3<R> n, R xi1, R xi2)
 {
-    const R pi = Consts<R>::pi;
-    R theta = acos(R(1) - xi1), phi = R(2) * pi * xi2;
-    R ct = cos(theta), st = sin(theta);
-    V3<R> res = {ct * cos(phi), st, -ct * sin(phi)};
-    // Y x (n - Y) = (n.z, 0, -n.x) exactly
-    V3<R> axis = {n.z, R(0), -n.x};
-    R z2 = axis.x * axis.x + axis.y * axis.y + axis.z * axis.z;
-    R angle = acos(n.y);
-    if (z2 > R(0))
+    R ct = R(1) - xi1;
+    R st = sqrt(xi1 * (R(2) - xi1));
+    R sp, cp;
+    sincospi_(R(2) * xi2, sp, cp);
+    V3<R> v = {ct * cp, st, -ct * sp};
+    R s2 = n.x * n.x + n.z * n.z;
+    if (s2 > R(0))
     {
-        R nn = sqrt(z2);
-        axis = {axis.x / nn, axis.y / nn, axis.z / nn};
+        R inv = rsqrt_(s2);
+        R kx = n.z * inv, kz = -n.x * inv;
+        R sn = s2 * inv, cs = n.y;
+        R kdv = (kx * v.x + kz * v.z) * (R(1) - cs);
+        return {v.x * cs - kz * v.y * sn + kx * kdv, v.y * cs + (kz * v.x - kx * v.z) * sn, v.z * cs + kx * v.y * sn + kz * kdv};
     }
-    else
-    {
-        axis = {R(1), R(0), R(0)};
-        if (fabs(n.y - R(1)) < R(1e-10))
-            angle = R(0);
-        else if (fabs(n.y + R(1)) < R(1e-10))
-            angle = pi;
-    }
-    V3<R> av = axis * angle;
-    R th = norm(av);
-    if (th < R(1e-7))
-        return res;
-    R h = th / R(2);
-    R qw = cos(h), s = sin(h);
-    V3<R> u = normalized(av);
-    V3<R> qv = {u.x * s, u.y * s, u.z * s};
-    V3<R> uv = cross(qv, res);
-    uv = uv + uv;
-    return res + qw * uv + cross(qv, uv);
+    // n = +Y: identity; n = -Y: half turn about X
+    if (n.y < R(0))
+        return {v.x, -v.y, -v.z};
+    return v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -230,9 +236,9 @@ template <class R> __device__ __forceinline__ V3<R> brdf_eval(const R *__restric
     R ca = dot(reflect(n, wi), wo);
     R ns = m[10];
     R pw = (ns == R(1)) ? ca : pow(ca, ns);
-    R k = (ns + R(2));
-    return {m[3] / pi + m[6] * k / (R(2) * pi) * pw, m[4] / pi + m[7] * k / (R(2) * pi) * pw,
-            m[5] / pi + m[8] * k / (R(2) * pi) * pw};
+    const R ipi = R(1) / pi;
+    R k = (ns + R(2)) * (R(0.5) * ipi) * pw;
+    return {m[3] * ipi + m[6] * k, m[4] * ipi + m[7] * k, m[5] * ipi + m[8] * k};
 }
 
 template <class R> __device__ __forceinline__ V3<R> bsdf_eval(const R *__restrict__ m, V3<R> wi, V3<R> wo, V3<R> n)
@@ -259,17 +265,17 @@ __device__ __forceinline__ void bxdf_sample(const R *__restrict__ m, V3<R> n, V3
     const R pi = Consts<R>::pi;
     if (m[12] == R(0))
     {
-        R pdf = R(1) / (R(2) * pi);
         wi = sample_hemisphere(n, xi1, xi2);
         V3<R> f = brdf_eval(m, -wi, wo, n);
-        R c = dot(n, wi);
-        coef = {f.x * c / pdf, f.y * c / pdf, f.z * c / pdf};
+        R c = dot(n, wi) * (R(2) * pi); // (n.wi) / pdf with pdf = 1 / (2 pi)
+        coef = {f.x * c, f.y * c, f.z * c};
     }
     else
     {
         R R0 = m[11];
         V3<R> mwo = -wo;
-        R Rf = R0 + (R(1) - R0) * pow(R(1) - fabs(dot(n, mwo)), R(5));
+        R x = R(1) - fabs(dot(n, mwo)), x2 = x * x;
+        R Rf = R0 + (R(1) - R0) * (x2 * x2 * x);
         if (xi1 < Rf)
             wi = reflect(n, mwo);
         else
@@ -278,9 +284,7 @@ __device__ __forceinline__ void bxdf_sample(const R *__restrict__ m, V3<R> n, V3
             if (has_nan(wi))
                 wi = reflect(n, mwo);
         }
-        R pdf = R(1) / (R(4) * pi);
-        R v = (R(1) * pdf * R(1)) / pdf;
-        coef = {v, v, v};
+        coef = {R(1), R(1), R(1)};
     }
 }
 
@@ -292,7 +296,7 @@ __device__ __forceinline__ R square_light_sample(const R *__restrict__ L, V3<R> 
     R area = L[16];
     V3<R> s = P0 + e10 * xi1;
     s = s + e21 * xi2;
-    V3<R> dir = normalized(ref - s);
+    V3<R> dir = fast_normalized(ref - s);
     R c = dot(dir, N);
     if (c <= R(0))
         return R(0);
@@ -316,13 +320,13 @@ __device__ __forceinline__ R sphere_light_sample(const R *__restrict__ L, V3<R> 
     if (dc > rad)
     {
         R max_theta = asin(rad / dc);
-        V3<R> to_light = normalized(C - ref);
+        V3<R> to_light = fast_normalized(C - ref);
         rd = -to_light;
         return R(1) / (R(2) * pi * (R(1) - cos(max_theta)));
     }
-    V3<R> u = normalized(V3<R>{xi1 - R(0.5), xi2 - R(0.5), xi3 - R(0.5)});
+    V3<R> u = fast_normalized(V3<R>{xi1 - R(0.5), xi2 - R(0.5), xi3 - R(0.5)});
     V3<R> lp = u * rad + C;
-    rd = normalized(ref - lp);
+    rd = fast_normalized(ref - lp);
     return R(1) / (R(4) * pi);
 }
 

@@ -37,12 +37,14 @@ template <class R> struct DScene
     int n_tris, n_mats, n_lights, n_square;
     int brute, enable_indirect, enable_bary, pad0;
     const R *tri_pre;          // [n_tris][12] in intersector order: p1, p1-p2, p1-p3, cofactors
+    const float *tri_pf;       // [n_tris][16] f32 prefilter records (all-triangles intersector)
     const int32_t *tri_face;   // intersector order -> face id
     const float *verts;        // [n_faces][9]  by face id
     const float *normals;      // [n_faces][9]
     const int32_t *mat_ids;    // [n_faces]
     const R *mats;             // [n_mats][MAT_STRIDE]
     const R *lights;           // [n_lights][LIGHT_STRIDE]
+    const R *face_nrm;         // [n_faces][4] by face id: shading normal + flag (1: use it; 0: interpolate)
     const BvhNode *nodes;
 };
 
@@ -83,6 +85,7 @@ template <class R> struct DState
 {
     R *ray_o[2][3], *ray_d[2][3]; // [2 queues][component][N]
     uint32_t *q_pid[2];           // [N]
+    int32_t *q_prim[2];           // [N] intersector-order triangle the ray starts on (-1: camera)
     int32_t *hit_prim;            // [N] intersector-order triangle index or -1
     R *hit_pt[3];                 // [N]
     R *stack_d;                   // [depth][3][N] by pid
@@ -119,16 +122,123 @@ template <class R> __device__ __forceinline__ R box_entry(const float *lo, const
     return (tmin - fabs(tmin) * k - k <= tmax + fabs(tmax) * k + k) ? tmin : R(-2);
 }
 
+// ---------------------------------------------------------------------------------------------
+// two-phase all-triangles intersector (f64).  Phase 1 walks every triangle in a wave-uniform loop
+// (records read through the scalar cache) with a division-free f32 Moller-Trumbore test whose
+// rounding error is bounded per triangle, and only REJECTS what the exact test is certain to reject
+// (or to ignore); the survivors form a per-lane bit mask.  Phase 2 runs the exact f64 test of the
+// reference on each lane's own candidates (triangle data from LDS), in ascending face order, so
+// decisions, distances and tie-breaking are bit-identical to testing all triangles exactly.
+//
+// Prefilter record (16 floats): p1[3], e1 = p2-p1 [3], e2 = p3-p1 [3], then with K = 128 * 2^-24:
+//   cu = K max|e2|, cv = K max|e1|, ct = K max|e1| max|e2|, cdet = K max|e1| max|e2|, max|p1|,
+//   1.001 (cu + cv), 1.001 cdet.
+// With T = max|o| + max|p1| the f32 numerators are off by at most cu T, cv T, ct T and the
+// determinant by cdet (|d| <= 1), from a forward error analysis of the fused dot/cross products
+// including the rounding of the inputs to f32 (each bound < 66 * 2^-24 * magnitudes).
+// ---------------------------------------------------------------------------------------------
+constexpr int PF_STRIDE = 16;
+constexpr int BRUTE_MAX_TRIS = 64; // candidate mask is one 64-bit word
+
+// LDS scratch of the intersecting kernels: the per-lane BVH stacks, or (all-triangles intersector)
+// a copy of the f64 triangle table that every lane indexes with its own candidate
+constexpr int LDS_WORDS_BRUTE = BRUTE_MAX_TRIS * 12 * 2;
+template <class R, bool BRUTE> __device__ __forceinline__ int *intersector_scratch(const DScene<R> &S, int *lds)
+{
+    if (BRUTE)
+    {
+        if constexpr (sizeof(R) == 8)
+        {
+            double *dst = reinterpret_cast<double *>(lds);
+            for (int k = threadIdx.x; k < S.n_tris * 12; k += BLOCK)
+                dst[k] = S.tri_pre[k];
+            __syncthreads();
+        }
+        return lds; // shared table: same pointer for every lane
+    }
+    return lds + threadIdx.x; // BVH: stack slot [level][lane]
+}
+
+__device__ __forceinline__ float flip(float x, uint32_t sbit) { return __uint_as_float(__float_as_uint(x) ^ sbit); }
+
+// skip: intersector-order index of the triangle the ray starts on (-1: none).  Hits of that
+// triangle are at distance ~0 and ignored by the exact test unless the ray grazes its plane, so it
+// is dropped only when the determinant is far from zero.
+__device__ __forceinline__ unsigned long long prefilter_mask(const float *__restrict__ PF, int n_tris, V3<double> o, V3<double> d,
+                                                             float tmin, float tmax, int skip)
+{
+#pragma clang fp contract(fast) // rounding differences are inside the error bounds of the records
+    const float ox = float(o.x), oy = float(o.y), oz = float(o.z);
+    const float dx = float(d.x), dy = float(d.y), dz = float(d.z);
+    const float To = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
+    uint32_t mlo = 0, mhi = 0;
+    for (int f = 0; f < n_tris; f++)
+    {
+        const float *__restrict__ P = PF + f * PF_STRIDE;
+        const float tx = ox - P[0], ty = oy - P[1], tz = oz - P[2];
+        const float e1x = P[3], e1y = P[4], e1z = P[5], e2x = P[6], e2y = P[7], e2z = P[8];
+        const float px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;
+        const float det = e1x * px + e1y * py + e1z * pz;
+        const float nu = tx * px + ty * py + tz * pz;
+        const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+        const float nv = dx * qx + dy * qy + dz * qz;
+        const float nt = e2x * qx + e2y * qy + e2z * qz;
+        const uint32_t sbit = __float_as_uint(det) & 0x80000000u;
+        const float A = fabsf(det);
+        const float T = To + P[13];
+        const float Ed = P[12];
+        const float su = flip(nu, sbit), sv = flip(nv, sbit), st = flip(nt, sbit);
+        // barycentrics: min(beta, gamma, alpha) numerators, each lifted by its error bound
+        const float ub = fmaf(P[9], T, su), vb = fmaf(P[10], T, sv);
+        const float ab = fmaf(P[14], T, (A - su - sv) + P[15]); // P[14] = 1.001 (cu + cv), P[15] = 1.001 cdet
+        const float slack = 1e-6f * (A + Ed);
+        const bool rej = (fminf(fminf(ub, vb), ab) < -slack) | (fmaf(P[11], T, st) < tmin * (A - Ed)) |
+                         (fmaf(-P[11], T, st) > tmax * (A + Ed));
+        bool keep = !((A > Ed) & rej);
+        if (f == skip && A > 1024.0f * Ed)
+            keep = false;
+        if (f < 32)
+            mlo |= keep ? (1u << f) : 0u;
+        else
+            mhi |= keep ? (1u << (f - 32)) : 0u;
+    }
+    return ((unsigned long long)mhi << 32) | mlo;
+}
+
 // closest hit.  Returns the intersector-order triangle index (or -1) and the hit point.
 // Winner = smallest |p - o| among accepted hits with |p - o| > self_eps; ties -> lowest face id.
 template <class R, bool BRUTE>
-__device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d, V3<R> &pt, int *stk)
+__device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d, V3<R> &pt, int *stk, int skip = -1)
 {
     R best = Consts<R>::big;
     int target = -1;
     const R self_eps = Consts<R>::self_eps;
     if (BRUTE)
     {
+        if constexpr (sizeof(R) == 8)
+        {
+            // stk points at this lane's view of the LDS copy of tri_pre (see load_tris_to_lds)
+            const double *lds_tri = reinterpret_cast<const double *>(stk);
+            unsigned long long mask = prefilter_mask(S.tri_pf, S.n_tris, o, d, 9e-7f, __builtin_inff(), skip);
+            while (mask)
+            {
+                const int f = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                R t;
+                if (tri_test(lds_tri + f * 12, o, d, t))
+                {
+                    V3<R> p = o + t * d;
+                    R dist = norm(p - o);
+                    if (dist < best && dist > self_eps)
+                    {
+                        best = dist;
+                        target = f;
+                        pt = p;
+                    }
+                }
+            }
+            return target;
+        }
         const R *__restrict__ T = S.tri_pre;
         for (int f = 0; f < S.n_tris; f++)
         {
@@ -213,13 +323,30 @@ __device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d,
 }
 
 // segment visibility p1 -> p2: blocked iff some triangle has self_eps < t < |p1 - p2| - self_eps
-template <class R, bool BRUTE> __device__ __forceinline__ bool visible(const DScene<R> &S, V3<R> p1, V3<R> p2, int *stk)
+template <class R, bool BRUTE> __device__ __forceinline__ bool visible(const DScene<R> &S, V3<R> p1, V3<R> p2, int *stk, int skip = -1)
 {
     const R self_eps = Consts<R>::self_eps;
     R dist = norm(p1 - p2);
     V3<R> dir = normalized(p2 - p1);
     if (BRUTE)
     {
+        if constexpr (sizeof(R) == 8)
+        {
+            const double *lds_tri = reinterpret_cast<const double *>(stk);
+            // blockers have self_eps < t < dist - self_eps: drop what surely lies outside (0.9e-6, dist)
+            const float far = float(dist) * 1.00001f + 1e-30f;
+            unsigned long long mask = prefilter_mask(S.tri_pf, S.n_tris, p1, dir, 9e-7f, far, skip);
+            bool blocked = false;
+            while (mask && !blocked)
+            {
+                const int f = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                R t;
+                if (tri_test(lds_tri + f * 12, p1, dir, t) && t < dist - self_eps && t > self_eps)
+                    blocked = true;
+            }
+            return !blocked;
+        }
         const R *__restrict__ T = S.tri_pre;
         bool blocked = false;
         for (int f = 0; f < S.n_tris; f++)
@@ -322,7 +449,8 @@ __global__ void __launch_bounds__(BLOCK)
     k_raycast(DScene<R> S, DCamera cam, int from_camera, const double *__restrict__ ro, const double *__restrict__ rd,
               int64_t n, int32_t *__restrict__ face_ids, double *__restrict__ pts)
 {
-    __shared__ int stk[BRUTE ? 1 : BVH_STACK * BLOCK];
+    __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : BVH_STACK * BLOCK];
+    int *stk = intersector_scratch<R, BRUTE>(S, lds_raw); // all threads: contains a barrier
     int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n)
         return;
@@ -335,7 +463,7 @@ __global__ void __launch_bounds__(BLOCK)
         d = {R(rd[i * 3]), R(rd[i * 3 + 1]), R(rd[i * 3 + 2])};
     }
     V3<R> p = {R(0), R(0), R(0)};
-    int k = closest_hit<R, BRUTE>(S, o, d, p, stk + threadIdx.x);
+    int k = closest_hit<R, BRUTE>(S, o, d, p, stk);
     face_ids[i] = k < 0 ? -1 : S.tri_face[k];
     if (pts)
     {
@@ -350,13 +478,14 @@ template <class R, bool BRUTE>
 __global__ void __launch_bounds__(BLOCK)
     k_vistest(DScene<R> S, const double *__restrict__ p1, const double *__restrict__ p2, int64_t n, int32_t *__restrict__ vis)
 {
-    __shared__ int stk[BRUTE ? 1 : BVH_STACK * BLOCK];
+    __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : BVH_STACK * BLOCK];
+    int *stk = intersector_scratch<R, BRUTE>(S, lds_raw); // all threads: contains a barrier
     int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n)
         return;
     V3<R> a = {R(p1[i * 3]), R(p1[i * 3 + 1]), R(p1[i * 3 + 2])};
     V3<R> b = {R(p2[i * 3]), R(p2[i * 3 + 1]), R(p2[i * 3 + 2])};
-    vis[i] = visible<R, BRUTE>(S, a, b, stk + threadIdx.x) ? 1 : 0;
+    vis[i] = visible<R, BRUTE>(S, a, b, stk) ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -385,12 +514,14 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_raygen(DCamera cam
     st.ray_o[0][0][pid] = o.x, st.ray_o[0][1][pid] = o.y, st.ray_o[0][2][pid] = o.z;
     st.ray_d[0][0][pid] = d.x, st.ray_d[0][1][pid] = d.y, st.ray_d[0][2][pid] = d.z;
     st.q_pid[0][pid] = uint32_t(pid);
+    st.q_prim[0][pid] = -1;
     st.path_state[pid] = uint32_t(B.depth) << 16; // default: survives every bounce, zero tail
 }
 
 template <class R, bool BRUTE> __global__ void __launch_bounds__(BLOCK) k_extend(DScene<R> S, DState<R> st, int bounce)
 {
-    __shared__ int stk[BRUTE ? 1 : BVH_STACK * BLOCK];
+    __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : BVH_STACK * BLOCK];
+    int *stk = intersector_scratch<R, BRUTE>(S, lds_raw); // all threads: contains a barrier
     const int q = bounce & 1, g = global_wave(), lane = lane_id();
     if (g >= st.n_regions)
         return;
@@ -405,7 +536,7 @@ template <class R, bool BRUTE> __global__ void __launch_bounds__(BLOCK) k_extend
             V3<R> o = {st.ray_o[q][0][i], st.ray_o[q][1][i], st.ray_o[q][2][i]};
             V3<R> d = {st.ray_d[q][0][i], st.ray_d[q][1][i], st.ray_d[q][2][i]};
             V3<R> p = {R(0), R(0), R(0)};
-            int k = closest_hit<R, BRUTE>(S, o, d, p, stk + threadIdx.x);
+            int k = closest_hit<R, BRUTE>(S, o, d, p, stk, st.q_prim[q][i]);
             st.hit_prim[i] = k;
             st.hit_pt[0][i] = p.x, st.hit_pt[1][i] = p.y, st.hit_pt[2][i] = p.z;
         }
@@ -435,12 +566,14 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S,
         const int64_t i = base + j;
         bool alive = false, defer = false;
         uint32_t pid = 0, mask = 0;
+        int hit_k = -1;
         V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
 
         if (active)
         {
             pid = st.q_pid[q][i];
             const int k = st.hit_prim[i];
+            hit_k = k;
             const int face = k < 0 ? -1 : S.tri_face[k];
             const int mat_id = face < 0 ? -1 : S.mat_ids[face];
             if (mat_id < 0)
@@ -454,21 +587,21 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S,
                 {
                     p = {st.hit_pt[0][i], st.hit_pt[1][i], st.hit_pt[2][i]};
                     V3<R> d = {st.ray_d[q][0][i], st.ray_d[q][1][i], st.ray_d[q][2][i]};
-                    const float *__restrict__ vp = S.verts + (size_t)face * 9;
-                    V3<R> a = {R(vp[0]), R(vp[1]), R(vp[2])}, b = {R(vp[3]), R(vp[4]), R(vp[5])}, c = {R(vp[6]), R(vp[7]), R(vp[8])};
-                    V3<R> nrm;
-                    if (S.enable_bary)
+                    // shading normal: precomputed per face when the face is flat (its three vertex
+                    // normals are equal) or when barycentric normals are off; else interpolated
+                    const R *__restrict__ fn = S.face_nrm + (size_t)face * 4;
+                    V3<R> nrm = {fn[0], fn[1], fn[2]};
+                    if (fn[3] == R(0))
                     {
+                        const float *__restrict__ vp = S.verts + (size_t)face * 9;
                         const float *__restrict__ np = S.normals + (size_t)face * 9;
+                        V3<R> a = {R(vp[0]), R(vp[1]), R(vp[2])}, b = {R(vp[3]), R(vp[4]), R(vp[5])}, c = {R(vp[6]), R(vp[7]), R(vp[8])};
                         V3<R> w = barycentric(p, a, b, c);
-                        V3<R> acc = {R(0), R(0), R(0)};
-                        acc = acc + w.x * V3<R>{R(np[0]), R(np[1]), R(np[2])};
+                        V3<R> acc = w.x * V3<R>{R(np[0]), R(np[1]), R(np[2])};
                         acc = acc + w.y * V3<R>{R(np[3]), R(np[4]), R(np[5])};
                         acc = acc + w.z * V3<R>{R(np[6]), R(np[7]), R(np[8])};
-                        nrm = normalized(acc);
+                        nrm = fast_normalized(acc);
                     }
-                    else
-                        nrm = normalized(cross(b - a, c - b));
 
                     // which pixel / sample this path belongs to (RNG key)
                     const int64_t pix = int64_t(pid) % B.n_pix;
@@ -501,7 +634,8 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S,
                             if (!(cn < R(0)))
                             {
                                 V3<R> f = bxdf_eval(m, rd, wo, nrm);
-                                term = {(L[1] * cn / pdf) * f.x, (L[2] * cn / pdf) * f.y, (L[3] * cn / pdf) * f.z};
+                                const R w = cn / pdf;
+                                term = {(L[1] * w) * f.x, (L[2] * w) * f.y, (L[3] * w) * f.z};
                                 valid = true;
                             }
                         }
@@ -546,6 +680,7 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S,
             st.ray_o[qn][0][slot] = p.x, st.ray_o[qn][1][slot] = p.y, st.ray_o[qn][2][slot] = p.z;
             st.ray_d[qn][0][slot] = wi.x, st.ray_d[qn][1][slot] = wi.y, st.ray_d[qn][2][slot] = wi.z;
             st.q_pid[qn][slot] = pid;
+            st.q_prim[qn][slot] = hit_k;
         }
         n_out += __popcll(am);
         // paths with NEE terms that need a visibility test -> this region's shadow list
@@ -569,7 +704,8 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S,
 
 template <class R, bool BRUTE> __global__ void __launch_bounds__(BLOCK) k_shadow(DScene<R> S, DBatch B, DState<R> st, int bounce)
 {
-    __shared__ int stk[BRUTE ? 1 : BVH_STACK * BLOCK];
+    __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : BVH_STACK * BLOCK];
+    int *stk = intersector_scratch<R, BRUTE>(S, lds_raw); // all threads: contains a barrier
     const int q = bounce & 1, g = global_wave(), lane = lane_id();
     if (g >= st.n_regions)
         return;
@@ -596,7 +732,7 @@ template <class R, bool BRUTE> __global__ void __launch_bounds__(BLOCK) k_shadow
                     const R *psrc = st.nee_p1 + (size_t)l * 3 * N;
                     V3<R> p1 = {psrc[i], psrc[N + i], psrc[2 * N + i]};
                     tests++;
-                    if (!visible<R, BRUTE>(S, p1, p2, stk + threadIdx.x))
+                    if (!visible<R, BRUTE>(S, p1, p2, stk, st.hit_prim[i]))
                         continue;
                 }
                 direct = direct + term;
