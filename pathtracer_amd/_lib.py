@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptx_amd.so")
+LIB_PATH = os.environ.get("PTX_LIB_OVERRIDE") or os.path.join(_HERE, "libptx_amd.so")
 
 PTX_OK = 0
 PTX_MODE_F64 = 0

@@ -247,7 +247,7 @@ template <class R> struct Context::Impl
             total += align(bytes);
             return off;
         };
-        size_t o_ray[2][6], o_pid[2], o_prim[2], o_hitprim, o_hitpt[3], o_sd, o_sc, o_ps, o_ni, o_nm, o_nc, o_np, o_cnt[2], o_ncnt, o_ws, o_stats;
+        size_t o_ray[2][6], o_pid[2], o_prim[2], o_hitprim, o_hitpt[3], o_sd, o_sc, o_ps, o_ni, o_nm, o_nc, o_cnt[2], o_ncnt, o_ws, o_stats;
         for (int q = 0; q < 2; q++)
         {
             for (int c = 0; c < 6; c++)
@@ -264,7 +264,6 @@ template <class R> struct Context::Impl
         o_ni = take(N * 4);
         o_nm = take(N * 4);
         o_nc = take(N * 3 * sizeof(R) * std::max(n_lights_deferred, 0));
-        o_np = take(N * 3 * sizeof(R) * std::max(n_lights_deferred, 0));
         // regions are at least 64 slots, so N / 64 + 1 bounds their number for any region size
         const size_t max_regions = N / 64 + 1;
         o_cnt[0] = take(max_regions * 4);
@@ -293,7 +292,6 @@ template <class R> struct Context::Impl
         st.nee_idx = reinterpret_cast<uint32_t *>(base + o_ni);
         st.nee_mask = reinterpret_cast<uint32_t *>(base + o_nm);
         st.nee_c = reinterpret_cast<R *>(base + o_nc);
-        st.nee_p1 = reinterpret_cast<R *>(base + o_np);
         st.cnt[0] = reinterpret_cast<uint32_t *>(base + o_cnt[0]);
         st.cnt[1] = reinterpret_cast<uint32_t *>(base + o_cnt[1]);
         st.nee_cnt = reinterpret_cast<uint32_t *>(base + o_ncnt);

@@ -230,12 +230,16 @@ constexpr int MAT_STRIDE = 16;
 // light: 24 scalars  type Li[3] | square: P0[3] e10[3] e21[3] N[3] area | sphere: C[3] radius
 constexpr int LIGHT_STRIDE = 24;
 
+// kept out of line: the f64 pow is long and only glossy materials (Ns != 1) reach it
+__device__ __attribute__((noinline)) double pow_outlined(double x, double y) { return pow(x, y); }
+__device__ __attribute__((noinline)) float pow_outlined(float x, float y) { return powf(x, y); }
+
 template <class R> __device__ __forceinline__ V3<R> brdf_eval(const R *__restrict__ m, V3<R> wi, V3<R> wo, V3<R> n)
 {
     const R pi = Consts<R>::pi;
     R ca = dot(reflect(n, wi), wo);
     R ns = m[10];
-    R pw = (ns == R(1)) ? ca : pow(ca, ns);
+    R pw = (ns == R(1)) ? ca : pow_outlined(ca, ns);
     const R ipi = R(1) / pi;
     R k = (ns + R(2)) * (R(0.5) * ipi) * pw;
     return {m[3] * ipi + m[6] * k, m[4] * ipi + m[7] * k, m[5] * ipi + m[8] * k};
@@ -289,21 +293,28 @@ __device__ __forceinline__ void bxdf_sample(const R *__restrict__ m, V3<R> n, V3
 }
 
 // square light: uniform point on the parallelogram, one-sided; returns pdf (0 = skip)
+template <class R> __device__ __forceinline__ V3<R> square_light_point(const R *__restrict__ L, R xi1, R xi2)
+{
+    V3<R> P0 = {L[4], L[5], L[6]}, e10 = {L[7], L[8], L[9]}, e21 = {L[10], L[11], L[12]};
+    V3<R> s = P0 + e10 * xi1;
+    return s + e21 * xi2;
+}
 template <class R>
 __device__ __forceinline__ R square_light_sample(const R *__restrict__ L, V3<R> ref, R xi1, R xi2, V3<R> &ro, V3<R> &rd)
 {
-    V3<R> P0 = {L[4], L[5], L[6]}, e10 = {L[7], L[8], L[9]}, e21 = {L[10], L[11], L[12]}, N = {L[13], L[14], L[15]};
+    V3<R> N = {L[13], L[14], L[15]};
     R area = L[16];
-    V3<R> s = P0 + e10 * xi1;
-    s = s + e21 * xi2;
-    V3<R> dir = fast_normalized(ref - s);
+    V3<R> s = square_light_point(L, xi1, xi2);
+    V3<R> g = ref - s;
+    R z = g.x * g.x + g.y * g.y + g.z * g.z; // squared distance, also the normalisation of the direction
+    R k = z > R(0) ? rsqrt_(z) : R(1);
+    V3<R> dir = {g.x * k, g.y * k, g.z * k};
     R c = dot(dir, N);
     if (c <= R(0))
         return R(0);
     ro = s;
     rd = dir;
-    R r = norm(s - ref);
-    return r * r / (area * c) * (R(1) / (R(2) * Consts<R>::pi));
+    return z / (area * c) * (R(1) / (R(2) * Consts<R>::pi));
 }
 
 // sphere light: the returned ray starts at the shaded point itself (so it is never shadowed) and

@@ -96,7 +96,6 @@ template <class R> struct DState
     uint32_t *nee_idx;            // [N] region-wise dense list of slots with pending tests
     uint32_t *nee_mask;           // [N] by slot: bit l = light l needs a visibility test
     R *nee_c;                     // [n_lights][3][N] by slot: per-light contribution
-    R *nee_p1;                    // [n_lights][3][N] by slot: light sample point
     uint32_t *cnt[2];             // [n_regions] live rays of each region, per queue buffer
     uint32_t *nee_cnt;            // [n_regions] pending-NEE paths of each region
     unsigned long long *wave_stats; // [n_regions][4] segments, shadow tests, wave iterations, spare
@@ -548,6 +547,17 @@ template <class R, bool BRUTE> __global__ void __launch_bounds__(BLOCK) k_extend
     }
 }
 
+// RNG key of a path: which image pixel and global sample index the path slot `pid` belongs to
+__device__ __forceinline__ uint64_t path_rng_key(const DBatch &B, uint32_t pid, uint32_t &sample)
+{
+    const int64_t pix = int64_t(pid) % B.n_pix;
+    const int s_local = int(int64_t(pid) / B.n_pix);
+    const int lr = B.row0 + int(pix / B.n_cols), col = B.col0 + int(pix % B.n_cols);
+    const uint32_t pixel = uint32_t(local_row_to_image_row(B, lr)) * uint32_t(B.image_width) + uint32_t(col);
+    sample = uint32_t(B.sample0 + s_local);
+    return rng_pixel_key(B.seed, pixel);
+}
+
 template <class R> __global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S, DBatch B, DState<R> st, int bounce)
 {
     const int q = bounce & 1, qn = q ^ 1, g = global_wave(), lane = lane_id();
@@ -558,129 +568,125 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S,
     const int64_t N = st.N;
     int n_out = 0, n_nee = 0; // wave-uniform running counts of this region's two output lists
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const bool last_bounce = bounce + 1 >= B.depth;
 
     for (int j0 = 0; j0 < n; j0 += 64)
     {
         const int j = j0 + lane;
-        const bool active = j < n;
         const int64_t i = base + j;
-        bool alive = false, defer = false;
-        uint32_t pid = 0, mask = 0;
-        int hit_k = -1;
-        V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
-
-        if (active)
+        // ---- termination rules (miss / no material -> tail 0; emitter -> tail Ka) ----------------
+        bool shaded = false;
+        uint32_t pid = 0;
+        int hit_k = -1, face = -1;
+        const R *__restrict__ m = S.mats;
+        if (j < n)
         {
             pid = st.q_pid[q][i];
-            const int k = st.hit_prim[i];
-            hit_k = k;
-            const int face = k < 0 ? -1 : S.tri_face[k];
+            hit_k = st.hit_prim[i];
+            face = hit_k < 0 ? -1 : S.tri_face[hit_k];
             const int mat_id = face < 0 ? -1 : S.mat_ids[face];
             if (mat_id < 0)
-                st.path_state[pid] = uint32_t(bounce) << 16; // miss or no material: tail 0
+                st.path_state[pid] = uint32_t(bounce) << 16;
             else
             {
-                const R *__restrict__ m = S.mats + (size_t)mat_id * MAT_STRIDE;
+                m = S.mats + (size_t)mat_id * MAT_STRIDE;
                 if (m[13] != R(0))
-                    st.path_state[pid] = (uint32_t(bounce) << 16) | uint32_t(mat_id + 1); // emitter: tail Ka
+                    st.path_state[pid] = (uint32_t(bounce) << 16) | uint32_t(mat_id + 1);
                 else
-                {
-                    p = {st.hit_pt[0][i], st.hit_pt[1][i], st.hit_pt[2][i]};
-                    V3<R> d = {st.ray_d[q][0][i], st.ray_d[q][1][i], st.ray_d[q][2][i]};
-                    // shading normal: precomputed per face when the face is flat (its three vertex
-                    // normals are equal) or when barycentric normals are off; else interpolated
-                    const R *__restrict__ fn = S.face_nrm + (size_t)face * 4;
-                    V3<R> nrm = {fn[0], fn[1], fn[2]};
-                    if (fn[3] == R(0))
-                    {
-                        const float *__restrict__ vp = S.verts + (size_t)face * 9;
-                        const float *__restrict__ np = S.normals + (size_t)face * 9;
-                        V3<R> a = {R(vp[0]), R(vp[1]), R(vp[2])}, b = {R(vp[3]), R(vp[4]), R(vp[5])}, c = {R(vp[6]), R(vp[7]), R(vp[8])};
-                        V3<R> w = barycentric(p, a, b, c);
-                        V3<R> acc = w.x * V3<R>{R(np[0]), R(np[1]), R(np[2])};
-                        acc = acc + w.y * V3<R>{R(np[3]), R(np[4]), R(np[5])};
-                        acc = acc + w.z * V3<R>{R(np[6]), R(np[7]), R(np[8])};
-                        nrm = fast_normalized(acc);
-                    }
-
-                    // which pixel / sample this path belongs to (RNG key)
-                    const int64_t pix = int64_t(pid) % B.n_pix;
-                    const int s_local = int(int64_t(pid) / B.n_pix);
-                    const int lr = B.row0 + int(pix / B.n_cols), col = B.col0 + int(pix % B.n_cols);
-                    const uint32_t pixel = uint32_t(local_row_to_image_row(B, lr)) * uint32_t(B.image_width) + uint32_t(col);
-                    const uint32_t sample = uint32_t(B.sample0 + s_local);
-                    const uint64_t key = rng_pixel_key(B.seed, pixel);
-                    const V3<R> wo = -d;
-
-                    // NEE over all lights, in order
-                    V3<R> direct = {R(0), R(0), R(0)};
-                    for (int l = 0; l < S.n_lights; l++)
-                    {
-                        const R *__restrict__ L = S.lights + (size_t)l * LIGHT_STRIDE;
-                        V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
-                        R pdf;
-                        const R x1 = rng_draw<R>(key, sample, bounce, 4 * l + 0);
-                        const R x2 = rng_draw<R>(key, sample, bounce, 4 * l + 1);
-                        const bool square = L[0] == R(0);
-                        if (square)
-                            pdf = square_light_sample(L, p, x1, x2, ro, rd);
-                        else
-                            pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bounce, 4 * l + 2), ro, rd);
-                        V3<R> term = {R(0), R(0), R(0)};
-                        bool valid = false;
-                        if (!(pdf < R(1e-10)))
-                        {
-                            R cn = dot(nrm, -rd);
-                            if (!(cn < R(0)))
-                            {
-                                V3<R> f = bxdf_eval(m, rd, wo, nrm);
-                                const R w = cn / pdf;
-                                term = {(L[1] * w) * f.x, (L[2] * w) * f.y, (L[3] * w) * f.z};
-                                valid = true;
-                            }
-                        }
-                        if (S.n_square > 0)
-                        {
-                            R *cdst = st.nee_c + (size_t)l * 3 * N, *pdst = st.nee_p1 + (size_t)l * 3 * N;
-                            cdst[i] = term.x, cdst[N + i] = term.y, cdst[2 * N + i] = term.z;
-                            pdst[i] = ro.x, pdst[N + i] = ro.y, pdst[2 * N + i] = ro.z;
-                        }
-                        if (valid && square)
-                            mask |= 1u << l;
-                        direct = direct + term;
-                    }
-                    defer = mask != 0;
-                    if (!defer)
-                    {
-                        R *D = st.stack_d + (size_t)bounce * 3 * N;
-                        D[pid] = direct.x, D[N + pid] = direct.y, D[2 * N + pid] = direct.z;
-                    }
-                    // next direction
-                    V3<R> coef = {R(0), R(0), R(0)};
-                    if (S.enable_indirect)
-                    {
-                        const R x1 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 0);
-                        const R x2 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 1);
-                        bxdf_sample(m, nrm, wo, x1, x2, wi, coef);
-                        alive = bounce + 1 < B.depth;
-                    }
-                    else
-                        st.path_state[pid] = uint32_t(bounce + 1) << 16;
-                    R *C = st.stack_c + (size_t)bounce * 3 * N;
-                    C[pid] = coef.x, C[N + pid] = coef.y, C[2 * N + pid] = coef.z;
-                }
+                    shaded = true;
             }
         }
-
-        // survivors -> front of this region in the other queue buffer
+        const bool alive = shaded && S.enable_indirect && !last_bounce;
         const unsigned long long am = __ballot(alive);
-        if (alive)
+        bool defer = false;
+        uint32_t mask = 0;
+
+        if (shaded)
         {
-            const int64_t slot = base + n_out + __popcll(am & lt_mask);
-            st.ray_o[qn][0][slot] = p.x, st.ray_o[qn][1][slot] = p.y, st.ray_o[qn][2][slot] = p.z;
-            st.ray_d[qn][0][slot] = wi.x, st.ray_d[qn][1][slot] = wi.y, st.ray_d[qn][2][slot] = wi.z;
-            st.q_pid[qn][slot] = pid;
-            st.q_prim[qn][slot] = hit_k;
+            const V3<R> p = {st.hit_pt[0][i], st.hit_pt[1][i], st.hit_pt[2][i]};
+            const V3<R> wo = {-st.ray_d[q][0][i], -st.ray_d[q][1][i], -st.ray_d[q][2][i]};
+            // shading normal: precomputed per face when the face is flat (its three vertex normals
+            // are equal) or when barycentric normals are off; else interpolated
+            const R *__restrict__ fn = S.face_nrm + (size_t)face * 4;
+            V3<R> nrm = {fn[0], fn[1], fn[2]};
+            if (fn[3] == R(0))
+            {
+                const float *__restrict__ vp = S.verts + (size_t)face * 9;
+                const float *__restrict__ np = S.normals + (size_t)face * 9;
+                V3<R> a = {R(vp[0]), R(vp[1]), R(vp[2])}, b = {R(vp[3]), R(vp[4]), R(vp[5])}, c = {R(vp[6]), R(vp[7]), R(vp[8])};
+                V3<R> w = barycentric(p, a, b, c);
+                V3<R> acc = w.x * V3<R>{R(np[0]), R(np[1]), R(np[2])};
+                acc = acc + w.y * V3<R>{R(np[3]), R(np[4]), R(np[5])};
+                acc = acc + w.z * V3<R>{R(np[6]), R(np[7]), R(np[8])};
+                nrm = fast_normalized(acc);
+            }
+            uint32_t sample;
+            const uint64_t key = path_rng_key(B, pid, sample);
+
+            // ---- next direction first: the survivor leaves for its new slot right away ---------
+            V3<R> coef = {R(0), R(0), R(0)};
+            if (S.enable_indirect)
+            {
+                const R x1 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 0);
+                const R x2 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 1);
+                V3<R> wi;
+                bxdf_sample(m, nrm, wo, x1, x2, wi, coef);
+                if (alive)
+                {
+                    const int64_t slot = base + n_out + __popcll(am & lt_mask);
+                    st.ray_o[qn][0][slot] = p.x, st.ray_o[qn][1][slot] = p.y, st.ray_o[qn][2][slot] = p.z;
+                    st.ray_d[qn][0][slot] = wi.x, st.ray_d[qn][1][slot] = wi.y, st.ray_d[qn][2][slot] = wi.z;
+                    st.q_pid[qn][slot] = pid;
+                    st.q_prim[qn][slot] = hit_k;
+                }
+            }
+            else
+                st.path_state[pid] = uint32_t(bounce + 1) << 16;
+            R *C = st.stack_c + (size_t)bounce * 3 * N;
+            C[pid] = coef.x, C[N + pid] = coef.y, C[2 * N + pid] = coef.z;
+
+            // ---- NEE over all lights, in order ---------------------------------------------------
+            V3<R> direct = {R(0), R(0), R(0)};
+            for (int l = 0; l < S.n_lights; l++)
+            {
+                const R *__restrict__ L = S.lights + (size_t)l * LIGHT_STRIDE;
+                V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
+                R pdf;
+                const R x1 = rng_draw<R>(key, sample, bounce, 4 * l + 0);
+                const R x2 = rng_draw<R>(key, sample, bounce, 4 * l + 1);
+                const bool square = L[0] == R(0);
+                if (square)
+                    pdf = square_light_sample(L, p, x1, x2, ro, rd);
+                else
+                    pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bounce, 4 * l + 2), ro, rd);
+                V3<R> term = {R(0), R(0), R(0)};
+                bool valid = false;
+                if (!(pdf < R(1e-10)))
+                {
+                    R cn = dot(nrm, -rd);
+                    if (!(cn < R(0)))
+                    {
+                        V3<R> f = bxdf_eval(m, rd, wo, nrm);
+                        const R w = cn / pdf;
+                        term = {(L[1] * w) * f.x, (L[2] * w) * f.y, (L[3] * w) * f.z};
+                        valid = true;
+                    }
+                }
+                if (S.n_square > 0)
+                {
+                    R *cdst = st.nee_c + (size_t)l * 3 * N;
+                    cdst[i] = term.x, cdst[N + i] = term.y, cdst[2 * N + i] = term.z;
+                }
+                if (valid && square)
+                    mask |= 1u << l;
+                direct = direct + term;
+            }
+            defer = mask != 0;
+            if (!defer)
+            {
+                R *D = st.stack_d + (size_t)bounce * 3 * N;
+                D[pid] = direct.x, D[N + pid] = direct.y, D[2 * N + pid] = direct.z;
+            }
         }
         n_out += __popcll(am);
         // paths with NEE terms that need a visibility test -> this region's shadow list
@@ -722,6 +728,9 @@ template <class R, bool BRUTE> __global__ void __launch_bounds__(BLOCK) k_shadow
             const int64_t i = base + st.nee_idx[base + j];
             const uint32_t pid = st.q_pid[q][i], mask = st.nee_mask[i];
             const V3<R> p2 = {st.hit_pt[0][i], st.hit_pt[1][i], st.hit_pt[2][i]};
+            const int own = st.hit_prim[i];
+            uint32_t sample;
+            const uint64_t key = path_rng_key(B, pid, sample);
             V3<R> direct = {R(0), R(0), R(0)};
             for (int l = 0; l < nl; l++)
             {
@@ -729,10 +738,14 @@ template <class R, bool BRUTE> __global__ void __launch_bounds__(BLOCK) k_shadow
                 V3<R> term = {csrc[i], csrc[N + i], csrc[2 * N + i]};
                 if (mask & (1u << l))
                 {
-                    const R *psrc = st.nee_p1 + (size_t)l * 3 * N;
-                    V3<R> p1 = {psrc[i], psrc[N + i], psrc[2 * N + i]};
+                    // the light sample point is a pure function of the path's random numbers:
+                    // regenerated here instead of being carried through memory
+                    const R *__restrict__ L = S.lights + (size_t)l * LIGHT_STRIDE;
+                    const R x1 = rng_draw<R>(key, sample, bounce, 4 * l + 0);
+                    const R x2 = rng_draw<R>(key, sample, bounce, 4 * l + 1);
+                    const V3<R> p1 = square_light_point(L, x1, x2);
                     tests++;
-                    if (!visible<R, BRUTE>(S, p1, p2, stk, st.hit_prim[i]))
+                    if (!visible<R, BRUTE>(S, p1, p2, stk, own))
                         continue;
                 }
                 direct = direct + term;
@@ -763,8 +776,15 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_resolve(DScene<R> 
         const R *m = S.mats + (size_t)(tm - 1) * MAT_STRIDE;
         fr = m[0], fg = m[1], fb = m[2];
     }
-    for (int i = len - 1; i >= 0; i--)
+    // the loop runs over the longest stack of the wave so that, at every step, all lanes read the
+    // SAME stack level at consecutive path ids (each 64-byte sector of a level is fetched once)
+    int wlen = len;
+    for (int off = 32; off > 0; off >>= 1)
+        wlen = max(wlen, __shfl_xor(wlen, off, 64));
+    for (int i = wlen - 1; i >= 0; i--)
     {
+        if (i >= len)
+            continue;
         const R *D = st.stack_d + (size_t)i * 3 * N, *C = st.stack_c + (size_t)i * 3 * N;
         fr = D[pid] + C[pid] * fr;
         fg = D[N + pid] + C[N + pid] * fg;
