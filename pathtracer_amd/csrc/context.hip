@@ -67,7 +67,7 @@ inline unsigned blocks_for(int64_t n) { return static_cast<unsigned>(std::max<in
 // per-precision device tables + wavefront state
 template <class R> struct Context::Impl
 {
-    DeviceBuffer tri_pre, tri_pf, mats, lights, face_nrm;
+    DeviceBuffer tri_pre, tri_pf, mats, lights, tri_nrm;
     DeviceBuffer state_mem; // one slab carved into the DState arrays
     DState<R> st;
     int64_t capacity = 0;
@@ -193,8 +193,9 @@ template <class R> struct Context::Impl
         // (or when the OBJ carries no normals at all)
         std::vector<R> fn(static_cast<size_t>(std::max(F, 1)) * 4, R(0));
         const bool bary = sc.enable_bary_normal && sc.has_normals;
-        for (int f = 0; f < F; f++)
+        for (int k = 0; k < F; k++)
         {
+            const int f = brute ? k : bvh.tri_order[k];
             const float *v = &sc.verts[static_cast<size_t>(f) * 9];
             const float *n = &sc.normals[static_cast<size_t>(f) * 9];
             double g[3];
@@ -221,12 +222,12 @@ template <class R> struct Context::Impl
             if (use)
             {
                 double z = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
-                double k = z > 0 ? 1.0 / std::sqrt(z) : 1.0;
-                R *o = &fn[static_cast<size_t>(f) * 4];
-                o[0] = R(g[0] * k), o[1] = R(g[1] * k), o[2] = R(g[2] * k), o[3] = R(1);
+                double inv = z > 0 ? 1.0 / std::sqrt(z) : 1.0;
+                R *o = &fn[static_cast<size_t>(k) * 4];
+                o[0] = R(g[0] * inv), o[1] = R(g[1] * inv), o[2] = R(g[2] * inv), o[3] = R(1);
             }
         }
-        upload(face_nrm, fn, s);
+        upload(tri_nrm, fn, s);
         ready = true;
     }
 
@@ -283,7 +284,7 @@ template <class R> struct Context::Impl
             st.q_pid[q] = reinterpret_cast<uint32_t *>(base + o_pid[q]);
             st.q_prim[q] = reinterpret_cast<int32_t *>(base + o_prim[q]);
         }
-        st.hit_prim = reinterpret_cast<int32_t *>(base + o_hitprim);
+        st.hit_prim = reinterpret_cast<uint32_t *>(base + o_hitprim);
         for (int c = 0; c < 3; c++)
             st.hit_pt[c] = reinterpret_cast<R *>(base + o_hitpt[c]);
         st.stack_d = reinterpret_cast<R *>(base + o_sd);
@@ -306,7 +307,7 @@ template <class R> struct Context::Impl
 
 struct Context::Geometry
 {
-    DeviceBuffer tri_face, verts, normals, mat_ids, nodes;
+    DeviceBuffer tri_face, tri_mat, verts, normals, mat_ids, nodes;
 };
 
 Context::Context(int device) : device_(device)
@@ -345,8 +346,10 @@ void Context::build_accel(const Scene &sc)
         throw std::runtime_error("state: BVH deeper than the traversal stack");
     if (sc.n_square_lights() > 0 && static_cast<int>(sc.lights.size()) > MAX_LIGHTS)
         throw std::runtime_error("arg: at most 32 lights are supported when square lights are present");
-    if (sc.mats.size() > 65534)
-        throw std::runtime_error("arg: at most 65534 materials are supported");
+    if (static_cast<int>(sc.mats.size()) > MAX_MATS)
+        throw std::runtime_error("arg: at most 4094 materials are supported");
+    if (sc.n_tris() > MAX_TRIS)
+        throw std::runtime_error("arg: at most 1048574 triangles are supported");
     if (sc.depth > 4095)
         throw std::runtime_error("arg: Depth above 4095 is not supported");
     delete geo_;
@@ -355,6 +358,10 @@ void Context::build_accel(const Scene &sc)
     for (int k = 0; k < sc.n_tris(); k++)
         face[k] = brute_ ? k : bvh_.tri_order[k];
     upload(geo_->tri_face, face, s);
+    std::vector<int32_t> tmat(std::max(sc.n_tris(), 1), -1);
+    for (int k = 0; k < sc.n_tris(); k++)
+        tmat[k] = sc.mat_ids[face[k]];
+    upload(geo_->tri_mat, tmat, s);
     upload(geo_->verts, sc.verts, s);
     upload(geo_->normals, sc.normals, s);
     upload(geo_->mat_ids, sc.mat_ids, s);
@@ -366,7 +373,7 @@ void Context::build_accel(const Scene &sc)
 }
 
 template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::Geometry &g, const void *tri_pre, const void *tri_pf,
-                                                 const void *mats, const void *lights, const void *face_nrm, bool brute)
+                                                 const void *mats, const void *lights, const void *tri_nrm, bool brute)
 {
     DScene<R> S;
     S.n_tris = sc.n_tris();
@@ -385,7 +392,8 @@ template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::
     S.mat_ids = static_cast<const int32_t *>(g.mat_ids.p);
     S.mats = static_cast<const R *>(mats);
     S.lights = static_cast<const R *>(lights);
-    S.face_nrm = static_cast<const R *>(face_nrm);
+    S.tri_nrm = static_cast<const R *>(tri_nrm);
+    S.tri_mat = static_cast<const int32_t *>(g.tri_mat.p);
     S.nodes = static_cast<const BvhNode *>(g.nodes.p);
     return S;
 }
@@ -449,7 +457,7 @@ void Context::raycast(const double *ro, const double *rd, int64_t n, int32_t *id
     double *pp = pts ? static_cast<double *>(d_pts.p) : nullptr;
     if (mode == PTX_MODE_F64_)
     {
-        auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->tri_pf.p, f64_->mats.p, f64_->lights.p, f64_->face_nrm.p, brute_);
+        auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->tri_pf.p, f64_->mats.p, f64_->lights.p, f64_->tri_nrm.p, brute_);
         if (brute_)
             hipLaunchKernelGGL((k_raycast<double, true>), grid, block, 0, s, S, cam, int(from_camera), po, pd, n, pi, pp);
         else
@@ -457,7 +465,7 @@ void Context::raycast(const double *ro, const double *rd, int64_t n, int32_t *id
     }
     else
     {
-        auto S = make_dscene<float>(scene_, *geo_, f32_->tri_pre.p, f32_->tri_pf.p, f32_->mats.p, f32_->lights.p, f32_->face_nrm.p, brute_);
+        auto S = make_dscene<float>(scene_, *geo_, f32_->tri_pre.p, f32_->tri_pf.p, f32_->mats.p, f32_->lights.p, f32_->tri_nrm.p, brute_);
         if (brute_)
             hipLaunchKernelGGL((k_raycast<float, true>), grid, block, 0, s, S, cam, int(from_camera), po, pd, n, pi, pp);
         else
@@ -481,7 +489,7 @@ void Context::vistest(const double *p1, const double *p2, int64_t n, int32_t *vi
     d1.alloc(n * 24), d2.alloc(n * 24), dv.alloc(n * 4);
     HIP_CHECK(hipMemcpyAsync(d1.p, p1, n * 24, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemcpyAsync(d2.p, p2, n * 24, hipMemcpyHostToDevice, s));
-    auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->tri_pf.p, f64_->mats.p, f64_->lights.p, f64_->face_nrm.p, brute_);
+    auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->tri_pf.p, f64_->mats.p, f64_->lights.p, f64_->tri_nrm.p, brute_);
     const dim3 grid(blocks_for(n)), block(BLOCK);
     if (brute_)
         hipLaunchKernelGGL((k_vistest<double, true>), grid, block, 0, s, S, static_cast<const double *>(d1.p),
@@ -620,7 +628,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     im.ensure_state(cap, depth, deferred, region);
     HIP_CHECK(hipMemsetAsync(im.st.stats, 0, sizeof(unsigned long long) * 8, s));
 
-    auto S = make_dscene<R>(sc, *geo_, im.tri_pre.p, im.tri_pf.p, im.mats.p, im.lights.p, im.face_nrm.p, brute_);
+    auto S = make_dscene<R>(sc, *geo_, im.tri_pre.p, im.tri_pf.p, im.mats.p, im.lights.p, im.tri_nrm.p, brute_);
     DCamera cam = make_camera(sc);
     RenderTimers *tm = o.profile ? &timers_ : nullptr;
 

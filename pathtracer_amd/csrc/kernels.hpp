@@ -30,6 +30,10 @@ namespace ptx
 
 constexpr int BLOCK = 256;      // threads per workgroup (4 waves)
 constexpr int BVH_STACK = 48;   // per-lane traversal stack entries (LDS)
+// hit word packing: 20 bits of intersector-order triangle index + 1, 12 bits of material id + 1
+constexpr uint32_t HIT_TRI_MASK = 0xFFFFFu;
+constexpr int HIT_MAT_SHIFT = 20;
+constexpr int MAX_TRIS = (1 << 20) - 2, MAX_MATS = (1 << 12) - 2;
 constexpr int MAX_LIGHTS = 32;  // lights per scene when NEE terms are deferred to k_shadow (mask bits)
 
 template <class R> struct DScene
@@ -44,7 +48,8 @@ template <class R> struct DScene
     const int32_t *mat_ids;    // [n_faces]
     const R *mats;             // [n_mats][MAT_STRIDE]
     const R *lights;           // [n_lights][LIGHT_STRIDE]
-    const R *face_nrm;         // [n_faces][4] by face id: shading normal + flag (1: use it; 0: interpolate)
+    const R *tri_nrm;          // [n_tris][4] intersector order: shading normal + flag (1: use it; 0: interpolate)
+    const int32_t *tri_mat;    // [n_tris] intersector order: material id (-1: none)
     const BvhNode *nodes;
 };
 
@@ -86,7 +91,7 @@ template <class R> struct DState
     R *ray_o[2][3], *ray_d[2][3]; // [2 queues][component][N]
     uint32_t *q_pid[2];           // [N]
     int32_t *q_prim[2];           // [N] intersector-order triangle the ray starts on (-1: camera)
-    int32_t *hit_prim;            // [N] intersector-order triangle index or -1
+    uint32_t *hit_prim;           // [N] hit word: 0 = miss, else (triangle + 1) | (material + 1) << 20
     R *hit_pt[3];                 // [N]
     R *stack_d;                   // [depth][3][N] by pid
     R *stack_c;                   // [depth][3][N] by pid
@@ -536,7 +541,7 @@ template <class R, bool BRUTE> __global__ void __launch_bounds__(BLOCK) k_extend
             V3<R> d = {st.ray_d[q][0][i], st.ray_d[q][1][i], st.ray_d[q][2][i]};
             V3<R> p = {R(0), R(0), R(0)};
             int k = closest_hit<R, BRUTE>(S, o, d, p, stk, st.q_prim[q][i]);
-            st.hit_prim[i] = k;
+            st.hit_prim[i] = k < 0 ? 0u : (uint32_t(k + 1) | (uint32_t(S.tri_mat[k] + 1) << HIT_MAT_SHIFT));
             st.hit_pt[0][i] = p.x, st.hit_pt[1][i] = p.y, st.hit_pt[2][i] = p.z;
         }
     }
@@ -570,31 +575,49 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S,
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const bool last_bounce = bounce + 1 >= B.depth;
 
+    // first-level loads of one queue slot; issued one iteration ahead of their use so that the
+    // memory latency of iteration k+1 overlaps the arithmetic of iteration k
+    struct Item
+    {
+        uint32_t pid, hit;
+        V3<R> p, d;
+    };
+    auto load_item = [&](int jj) {
+        Item it;
+        it.pid = 0, it.hit = 0;
+        it.p = {R(0), R(0), R(0)}, it.d = {R(0), R(0), R(0)};
+        if (jj < n)
+        {
+            const int64_t ii = base + jj;
+            it.pid = st.q_pid[q][ii];
+            it.hit = st.hit_prim[ii];
+            it.p = {st.hit_pt[0][ii], st.hit_pt[1][ii], st.hit_pt[2][ii]};
+            it.d = {st.ray_d[q][0][ii], st.ray_d[q][1][ii], st.ray_d[q][2][ii]};
+        }
+        return it;
+    };
+    Item next = load_item(lane);
+
     for (int j0 = 0; j0 < n; j0 += 64)
     {
         const int j = j0 + lane;
         const int64_t i = base + j;
+        const Item cur = next;
+        next = load_item(j + 64);
         // ---- termination rules (miss / no material -> tail 0; emitter -> tail Ka) ----------------
         bool shaded = false;
-        uint32_t pid = 0;
-        int hit_k = -1, face = -1;
-        const R *__restrict__ m = S.mats;
+        const uint32_t pid = cur.pid;
+        const int hit_k = int(cur.hit & HIT_TRI_MASK) - 1;
+        const int mat_id = int(cur.hit >> HIT_MAT_SHIFT) - 1;
+        const R *__restrict__ m = S.mats + (size_t)(mat_id < 0 ? 0 : mat_id) * MAT_STRIDE;
         if (j < n)
         {
-            pid = st.q_pid[q][i];
-            hit_k = st.hit_prim[i];
-            face = hit_k < 0 ? -1 : S.tri_face[hit_k];
-            const int mat_id = face < 0 ? -1 : S.mat_ids[face];
             if (mat_id < 0)
                 st.path_state[pid] = uint32_t(bounce) << 16;
+            else if (m[13] != R(0))
+                st.path_state[pid] = (uint32_t(bounce) << 16) | uint32_t(mat_id + 1);
             else
-            {
-                m = S.mats + (size_t)mat_id * MAT_STRIDE;
-                if (m[13] != R(0))
-                    st.path_state[pid] = (uint32_t(bounce) << 16) | uint32_t(mat_id + 1);
-                else
-                    shaded = true;
-            }
+                shaded = true;
         }
         const bool alive = shaded && S.enable_indirect && !last_bounce;
         const unsigned long long am = __ballot(alive);
@@ -603,14 +626,15 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S,
 
         if (shaded)
         {
-            const V3<R> p = {st.hit_pt[0][i], st.hit_pt[1][i], st.hit_pt[2][i]};
-            const V3<R> wo = {-st.ray_d[q][0][i], -st.ray_d[q][1][i], -st.ray_d[q][2][i]};
-            // shading normal: precomputed per face when the face is flat (its three vertex normals
+            const V3<R> p = cur.p;
+            const V3<R> wo = -cur.d;
+            // shading normal: precomputed per triangle when it is flat (its three vertex normals
             // are equal) or when barycentric normals are off; else interpolated
-            const R *__restrict__ fn = S.face_nrm + (size_t)face * 4;
+            const R *__restrict__ fn = S.tri_nrm + (size_t)hit_k * 4;
             V3<R> nrm = {fn[0], fn[1], fn[2]};
             if (fn[3] == R(0))
             {
+                const int face = S.tri_face[hit_k];
                 const float *__restrict__ vp = S.verts + (size_t)face * 9;
                 const float *__restrict__ np = S.normals + (size_t)face * 9;
                 V3<R> a = {R(vp[0]), R(vp[1]), R(vp[2])}, b = {R(vp[3]), R(vp[4]), R(vp[5])}, c = {R(vp[6]), R(vp[7]), R(vp[8])};
@@ -728,7 +752,7 @@ template <class R, bool BRUTE> __global__ void __launch_bounds__(BLOCK) k_shadow
             const int64_t i = base + st.nee_idx[base + j];
             const uint32_t pid = st.q_pid[q][i], mask = st.nee_mask[i];
             const V3<R> p2 = {st.hit_pt[0][i], st.hit_pt[1][i], st.hit_pt[2][i]};
-            const int own = st.hit_prim[i];
+            const int own = int(st.hit_prim[i] & HIT_TRI_MASK) - 1;
             uint32_t sample;
             const uint64_t key = path_rng_key(B, pid, sample);
             V3<R> direct = {R(0), R(0), R(0)};
