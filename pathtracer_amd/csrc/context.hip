@@ -524,7 +524,18 @@ static void run_batch(const DScene<R> &S, const DCamera &cam, const DBatch &B, D
         hipLaunchKernelGGL((k_extend<R, BRUTE>), grid_waves, block, 0, s, S, st, b);
         if (tm)
             tm->mark(s, RenderTimers::SHADE);
-        hipLaunchKernelGGL((k_shade<R>), grid_waves, block, 0, s, S, B, st, b);
+        {
+            const bool tab = S.n_mats <= SHADE_LDS_MATS && S.n_lights <= SHADE_LDS_LIGHTS;
+            const bool nrm = S.n_tris <= SHADE_LDS_TRIS;
+            if (tab && nrm)
+                hipLaunchKernelGGL((k_shade<R, true, true>), grid_waves, block, 0, s, S, B, st, b);
+            else if (tab)
+                hipLaunchKernelGGL((k_shade<R, true, false>), grid_waves, block, 0, s, S, B, st, b);
+            else if (nrm)
+                hipLaunchKernelGGL((k_shade<R, false, true>), grid_waves, block, 0, s, S, B, st, b);
+            else
+                hipLaunchKernelGGL((k_shade<R, false, false>), grid_waves, block, 0, s, S, B, st, b);
+        }
         if (S.n_square > 0)
         {
             if (tm)

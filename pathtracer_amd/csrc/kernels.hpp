@@ -563,8 +563,31 @@ __device__ __forceinline__ uint64_t path_rng_key(const DBatch &B, uint32_t pid, 
     return rng_pixel_key(B.seed, pixel);
 }
 
-template <class R> __global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S, DBatch B, DState<R> st, int bounce)
+// On gfx9-class ISAs vector loads and stores retire in order on ONE counter, so a load issued
+// after a store waits for that store to be acknowledged.  k_shade therefore issues all its global
+// loads at the top of an iteration (the queue slot, prefetched one iteration ahead) and reads the
+// small tables -- materials, lights, per-triangle normals -- from LDS copies (LDS has its own
+// counter).  TAB: materials and lights fit LDS; NRM: the per-triangle normal table fits too.
+constexpr int SHADE_LDS_MATS = 64, SHADE_LDS_LIGHTS = 32, SHADE_LDS_TRIS = 64;
+
+template <class R, bool TAB, bool NRM>
+__global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S, DBatch B, DState<R> st, int bounce)
 {
+    __shared__ R lds_mats[TAB ? SHADE_LDS_MATS * MAT_STRIDE : 1];
+    __shared__ R lds_lights[TAB ? SHADE_LDS_LIGHTS * LIGHT_STRIDE : 1];
+    __shared__ R lds_nrm[NRM ? SHADE_LDS_TRIS * 4 : 1];
+    if (TAB)
+    {
+        for (int k = threadIdx.x; k < S.n_mats * MAT_STRIDE; k += BLOCK)
+            lds_mats[k] = S.mats[k];
+        for (int k = threadIdx.x; k < S.n_lights * LIGHT_STRIDE; k += BLOCK)
+            lds_lights[k] = S.lights[k];
+    }
+    if (NRM)
+        for (int k = threadIdx.x; k < S.n_tris * 4; k += BLOCK)
+            lds_nrm[k] = S.tri_nrm[k];
+    if (TAB || NRM)
+        __syncthreads();
     const int q = bounce & 1, qn = q ^ 1, g = global_wave(), lane = lane_id();
     if (g >= st.n_regions)
         return;
@@ -609,7 +632,12 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S,
         const uint32_t pid = cur.pid;
         const int hit_k = int(cur.hit & HIT_TRI_MASK) - 1;
         const int mat_id = int(cur.hit >> HIT_MAT_SHIFT) - 1;
-        const R *__restrict__ m = S.mats + (size_t)(mat_id < 0 ? 0 : mat_id) * MAT_STRIDE;
+        const int mrow = (mat_id < 0 ? 0 : mat_id) * MAT_STRIDE;
+        const R *m; // the address space (LDS or global) is fixed at compile time
+        if constexpr (TAB)
+            m = lds_mats + mrow;
+        else
+            m = S.mats + mrow;
         if (j < n)
         {
             if (mat_id < 0)
@@ -630,9 +658,16 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S,
             const V3<R> wo = -cur.d;
             // shading normal: precomputed per triangle when it is flat (its three vertex normals
             // are equal) or when barycentric normals are off; else interpolated
-            const R *__restrict__ fn = S.tri_nrm + (size_t)hit_k * 4;
-            V3<R> nrm = {fn[0], fn[1], fn[2]};
-            if (fn[3] == R(0))
+            R fn0, fn1, fn2, fn3;
+            if (NRM)
+                fn0 = lds_nrm[hit_k * 4], fn1 = lds_nrm[hit_k * 4 + 1], fn2 = lds_nrm[hit_k * 4 + 2], fn3 = lds_nrm[hit_k * 4 + 3];
+            else
+            {
+                const R *__restrict__ fn = S.tri_nrm + (size_t)hit_k * 4;
+                fn0 = fn[0], fn1 = fn[1], fn2 = fn[2], fn3 = fn[3];
+            }
+            V3<R> nrm = {fn0, fn1, fn2};
+            if (fn3 == R(0))
             {
                 const int face = S.tri_face[hit_k];
                 const float *__restrict__ vp = S.verts + (size_t)face * 9;
@@ -673,7 +708,11 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S,
             V3<R> direct = {R(0), R(0), R(0)};
             for (int l = 0; l < S.n_lights; l++)
             {
-                const R *__restrict__ L = S.lights + (size_t)l * LIGHT_STRIDE;
+                const R *L;
+                if constexpr (TAB)
+                    L = lds_lights + l * LIGHT_STRIDE;
+                else
+                    L = S.lights + (size_t)l * LIGHT_STRIDE;
                 V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
                 R pdf;
                 const R x1 = rng_draw<R>(key, sample, bounce, 4 * l + 0);
