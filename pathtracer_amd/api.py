@@ -109,7 +109,8 @@ class Scene:
 class Context:
     """One GPU: device copy of a scene plus wavefront state."""
 
-    def __init__(self, device=0, stream=None, brute_force_limit=None, batch_paths=None, region_slots=None):
+    def __init__(self, device=0, stream=None, brute_force_limit=None, batch_paths=None, region_slots=None,
+                 paths_per_wave=None):
         L = _lib.lib()
         h = C.c_void_p()
         check(L.ptx_context_create(int(device), C.byref(h)))
@@ -123,6 +124,8 @@ class Context:
             check(L.ptx_context_set_option(self._h, b"default_batch_paths", int(batch_paths)))
         if region_slots is not None:
             check(L.ptx_context_set_option(self._h, b"region_slots", int(region_slots)))
+        if paths_per_wave is not None:
+            check(L.ptx_context_set_option(self._h, b"paths_per_wave", int(paths_per_wave)))
 
     def __del__(self):
         try:

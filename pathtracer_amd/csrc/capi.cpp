@@ -295,6 +295,8 @@ int ptx_context_set_option(ptx_context *c, const char *name, int64_t value)
         c->ctx->default_batch_paths = value;
     else if (n == "region_slots" && value >= 64 && value <= (1 << 20))
         c->ctx->region_slots = static_cast<int>(value);
+    else if (n == "paths_per_wave" && value >= 0 && value <= (1 << 24))
+        c->ctx->paths_per_wave = static_cast<int>(value);
     else
         return fail_arg("ptx_context_set_option: unknown option or bad value");
     return PTX_OK;

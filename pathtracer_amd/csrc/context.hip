@@ -7,6 +7,7 @@
 // to front into the per-pixel sums.
 #include "context.hpp"
 #include "kernels.hpp"
+#include "plane_records.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -67,7 +68,7 @@ inline unsigned blocks_for(int64_t n) { return static_cast<unsigned>(std::max<in
 // per-precision device tables + wavefront state
 template <class R> struct Context::Impl
 {
-    DeviceBuffer tri_pre, tri_pf, mats, lights, tri_nrm;
+    DeviceBuffer tri_pre, mats, lights, tri_nrm;
     DeviceBuffer state_mem; // one slab carved into the DState arrays
     DState<R> st;
     int64_t capacity = 0;
@@ -100,35 +101,6 @@ template <class R> struct Context::Impl
             o[11] = t0 - t1;
         }
         upload(tri_pre, pre, s);
-
-        // f32 prefilter records of the two-phase all-triangles intersector (see kernels.hpp)
-        std::vector<float> pf(static_cast<size_t>(std::max(F, 1)) * PF_STRIDE, 0.f);
-        if (brute)
-        {
-            const double K = 128.0 * std::ldexp(1.0, -24);
-            for (int k = 0; k < F; k++)
-            {
-                const float *v = &sc.verts[static_cast<size_t>(k) * 9];
-                float *o = &pf[static_cast<size_t>(k) * PF_STRIDE];
-                double e1m = 0, e2m = 0, p1m = 0;
-                for (int c = 0; c < 3; c++)
-                {
-                    double e1 = double(v[3 + c]) - double(v[c]), e2 = double(v[6 + c]) - double(v[c]);
-                    o[c] = v[c];
-                    o[3 + c] = static_cast<float>(e1);
-                    o[6 + c] = static_cast<float>(e2);
-                    e1m = std::max(e1m, std::fabs(e1)), e2m = std::max(e2m, std::fabs(e2));
-                    p1m = std::max(p1m, std::fabs(double(v[c])));
-                }
-                // bounds rounded up when narrowed to float
-                auto up = [](double x) { return std::nextafter(static_cast<float>(x), std::numeric_limits<float>::infinity()); };
-                o[9] = up(K * e2m), o[10] = up(K * e1m), o[11] = up(K * e1m * e2m), o[12] = up(K * e1m * e2m);
-                o[13] = up(p1m);
-                o[14] = up(1.001 * (double(o[9]) + double(o[10])));
-                o[15] = up(1.001 * double(o[12]));
-            }
-        }
-        upload(tri_pf, pf, s);
 
         std::vector<R> m(static_cast<size_t>(std::max<size_t>(sc.mats.size(), 1)) * MAT_STRIDE, R(0));
         for (size_t i = 0; i < sc.mats.size(); i++)
@@ -248,7 +220,7 @@ template <class R> struct Context::Impl
             total += align(bytes);
             return off;
         };
-        size_t o_ray[2][6], o_pid[2], o_prim[2], o_hitprim, o_hitpt[3], o_sd, o_sc, o_ps, o_ni, o_nm, o_nc, o_cnt[2], o_ncnt, o_ws, o_stats;
+        size_t o_ray[2][6], o_pid[2], o_prim[2], o_hitprim, o_hitpt[3], o_sd, o_sc, o_stk, o_ps, o_ni, o_nm, o_nc, o_cnt[2], o_ncnt, o_ws, o_stats;
         for (int q = 0; q < 2; q++)
         {
             for (int c = 0; c < 6; c++)
@@ -261,6 +233,7 @@ template <class R> struct Context::Impl
             o_hitpt[c] = take(N * sizeof(R));
         o_sd = take(N * 3 * sizeof(R) * depth);
         o_sc = take(N * 3 * sizeof(R) * depth);
+        o_stk = take(N * 6 * sizeof(R) * depth);
         o_ps = take(N * 4);
         o_ni = take(N * 4);
         o_nm = take(N * 4);
@@ -290,6 +263,7 @@ template <class R> struct Context::Impl
         st.stack_d = reinterpret_cast<R *>(base + o_sd);
         st.stack_c = reinterpret_cast<R *>(base + o_sc);
         st.path_state = reinterpret_cast<uint32_t *>(base + o_ps);
+        st.stack = reinterpret_cast<R *>(base + o_stk);
         st.nee_idx = reinterpret_cast<uint32_t *>(base + o_ni);
         st.nee_mask = reinterpret_cast<uint32_t *>(base + o_nm);
         st.nee_c = reinterpret_cast<R *>(base + o_nc);
@@ -308,6 +282,8 @@ template <class R> struct Context::Impl
 struct Context::Geometry
 {
     DeviceBuffer tri_face, tri_mat, verts, normals, mat_ids, nodes;
+    DeviceBuffer tri_pq, rec_tri, tri_rec; // plane records of the all-triangles intersector
+    int n_recs = 0;
 };
 
 Context::Context(int device) : device_(device)
@@ -339,7 +315,22 @@ void Context::build_accel(const Scene &sc)
     HIP_CHECK(hipSetDevice(device_));
     hipStream_t s = static_cast<hipStream_t>(stream_);
     scene_ = sc; // host copy (camera, tracer settings)
+    // all-triangles intersector: small scenes whose plane records fit the candidate mask
+    PlaneRecords pr;
     brute_ = sc.n_tris() <= std::min(brute_force_limit, BRUTE_MAX_TRIS);
+    if (brute_)
+    {
+        build_plane_records(sc.verts.data(), sc.n_tris(), pr);
+        brute_ = pr.n_recs <= BRUTE_MAX_RECS;
+    }
+    if (!brute_)
+    {
+        pr = PlaneRecords();
+        pr.rec.assign(PLANE_REC_STRIDE, 0.f);
+        pr.rec_tri.assign(64, -1);
+        pr.tri_rec.assign(1, 0);
+    }
+    static_assert(PLANE_REC_STRIDE == PQ_STRIDE, "record stride");
     bvh_ = Bvh();
     build_bvh(sc.verts.data(), sc.n_tris(), bvh_, 4);
     if (!brute_ && bvh_.max_depth + 2 > BVH_STACK)
@@ -366,13 +357,17 @@ void Context::build_accel(const Scene &sc)
     upload(geo_->normals, sc.normals, s);
     upload(geo_->mat_ids, sc.mat_ids, s);
     upload(geo_->nodes, bvh_.nodes, s);
+    upload(geo_->tri_pq, pr.rec, s);
+    upload(geo_->rec_tri, pr.rec_tri, s);
+    upload(geo_->tri_rec, pr.tri_rec, s);
+    geo_->n_recs = pr.n_recs;
     f64_->build_tables(sc, bvh_, brute_, s);
     f32_->build_tables(sc, bvh_, brute_, s);
     HIP_CHECK(hipStreamSynchronize(s));
     have_scene_ = true;
 }
 
-template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::Geometry &g, const void *tri_pre, const void *tri_pf,
+template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::Geometry &g, const void *tri_pre,
                                                  const void *mats, const void *lights, const void *tri_nrm, bool brute)
 {
     DScene<R> S;
@@ -383,9 +378,11 @@ template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::
     S.brute = brute;
     S.enable_indirect = sc.enable_indirect;
     S.enable_bary = sc.enable_bary_normal && sc.has_normals;
-    S.pad0 = 0;
+    S.n_recs = g.n_recs;
     S.tri_pre = static_cast<const R *>(tri_pre);
-    S.tri_pf = static_cast<const float *>(tri_pf);
+    S.tri_pq = static_cast<const float *>(g.tri_pq.p);
+    S.rec_tri = static_cast<const int32_t *>(g.rec_tri.p);
+    S.tri_rec = static_cast<const int32_t *>(g.tri_rec.p);
     S.tri_face = static_cast<const int32_t *>(g.tri_face.p);
     S.verts = static_cast<const float *>(g.verts.p);
     S.normals = static_cast<const float *>(g.normals.p);
@@ -457,7 +454,7 @@ void Context::raycast(const double *ro, const double *rd, int64_t n, int32_t *id
     double *pp = pts ? static_cast<double *>(d_pts.p) : nullptr;
     if (mode == PTX_MODE_F64_)
     {
-        auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->tri_pf.p, f64_->mats.p, f64_->lights.p, f64_->tri_nrm.p, brute_);
+        auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->mats.p, f64_->lights.p, f64_->tri_nrm.p, brute_);
         if (brute_)
             hipLaunchKernelGGL((k_raycast<double, true>), grid, block, 0, s, S, cam, int(from_camera), po, pd, n, pi, pp);
         else
@@ -465,7 +462,7 @@ void Context::raycast(const double *ro, const double *rd, int64_t n, int32_t *id
     }
     else
     {
-        auto S = make_dscene<float>(scene_, *geo_, f32_->tri_pre.p, f32_->tri_pf.p, f32_->mats.p, f32_->lights.p, f32_->tri_nrm.p, brute_);
+        auto S = make_dscene<float>(scene_, *geo_, f32_->tri_pre.p, f32_->mats.p, f32_->lights.p, f32_->tri_nrm.p, brute_);
         if (brute_)
             hipLaunchKernelGGL((k_raycast<float, true>), grid, block, 0, s, S, cam, int(from_camera), po, pd, n, pi, pp);
         else
@@ -489,7 +486,7 @@ void Context::vistest(const double *p1, const double *p2, int64_t n, int32_t *vi
     d1.alloc(n * 24), d2.alloc(n * 24), dv.alloc(n * 4);
     HIP_CHECK(hipMemcpyAsync(d1.p, p1, n * 24, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemcpyAsync(d2.p, p2, n * 24, hipMemcpyHostToDevice, s));
-    auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->tri_pf.p, f64_->mats.p, f64_->lights.p, f64_->tri_nrm.p, brute_);
+    auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->mats.p, f64_->lights.p, f64_->tri_nrm.p, brute_);
     const dim3 grid(blocks_for(n)), block(BLOCK);
     if (brute_)
         hipLaunchKernelGGL((k_vistest<double, true>), grid, block, 0, s, S, static_cast<const double *>(d1.p),
@@ -546,6 +543,36 @@ static void run_batch(const DScene<R> &S, const DCamera &cam, const DBatch &B, D
     if (tm)
         tm->mark(s, RenderTimers::OTHER);
     hipLaunchKernelGGL((k_resolve<R>), dim3(blocks_for(B.n_paths)), block, 0, s, S, B, st);
+    hipLaunchKernelGGL((k_accumulate<R>), dim3(blocks_for(B.n_pix)), block, 0, s, B, st, sum);
+    hipLaunchKernelGGL((k_reduce_stats<R>), dim3(1), block, 0, s, B, st);
+    if (tm)
+        tm->mark(s, RenderTimers::END);
+    HIP_CHECK(hipGetLastError());
+}
+
+template <class R, bool BRUTE>
+static void run_batch_persistent(const DScene<R> &S, const DCamera &cam, const DBatch &B, DState<R> &st, double *sum, hipStream_t s,
+                                 RenderTimers *tm, int paths_per_wave)
+{
+    const int64_t n_waves = (B.n_paths + paths_per_wave - 1) / paths_per_wave;
+    st.n_regions = static_cast<int>(n_waves);
+    const dim3 block(BLOCK);
+    const dim3 grid(blocks_for(n_waves * 64));
+    if (tm)
+        tm->mark(s, RenderTimers::EXTEND);
+    const bool tab = S.n_mats <= SHADE_LDS_MATS && S.n_lights <= SHADE_LDS_LIGHTS;
+    const bool nrm = S.n_tris <= SHADE_LDS_TRIS;
+    if (tab && nrm)
+        hipLaunchKernelGGL((k_trace<R, BRUTE, true, true>), grid, block, 0, s, S, cam, B, st, paths_per_wave);
+    else if (tab)
+        hipLaunchKernelGGL((k_trace<R, BRUTE, true, false>), grid, block, 0, s, S, cam, B, st, paths_per_wave);
+    else if (nrm)
+        hipLaunchKernelGGL((k_trace<R, BRUTE, false, true>), grid, block, 0, s, S, cam, B, st, paths_per_wave);
+    else
+        hipLaunchKernelGGL((k_trace<R, BRUTE, false, false>), grid, block, 0, s, S, cam, B, st, paths_per_wave);
+    if (tm)
+        tm->mark(s, RenderTimers::OTHER);
+    hipLaunchKernelGGL((k_resolve_records<R>), dim3(blocks_for(B.n_paths)), block, 0, s, S, B, st);
     hipLaunchKernelGGL((k_accumulate<R>), dim3(blocks_for(B.n_pix)), block, 0, s, B, st, sum);
     hipLaunchKernelGGL((k_reduce_stats<R>), dim3(1), block, 0, s, B, st);
     if (tm)
@@ -639,7 +666,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     im.ensure_state(cap, depth, deferred, region);
     HIP_CHECK(hipMemsetAsync(im.st.stats, 0, sizeof(unsigned long long) * 8, s));
 
-    auto S = make_dscene<R>(sc, *geo_, im.tri_pre.p, im.tri_pf.p, im.mats.p, im.lights.p, im.tri_nrm.p, brute_);
+    auto S = make_dscene<R>(sc, *geo_, im.tri_pre.p, im.mats.p, im.lights.p, im.tri_nrm.p, brute_);
     DCamera cam = make_camera(sc);
     RenderTimers *tm = o.profile ? &timers_ : nullptr;
 
@@ -664,7 +691,15 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
             B.seed = o.seed;
             B.n_pix = static_cast<int64_t>(nr) * n_cols;
             B.n_paths = B.n_pix * B.n_samples;
-            if (brute_)
+            if (paths_per_wave > 0)
+            {
+                const int ppw = std::max(64, paths_per_wave);
+                if (brute_)
+                    run_batch_persistent<R, true>(S, cam, B, im.st, d_sum, s, tm, ppw);
+                else
+                    run_batch_persistent<R, false>(S, cam, B, im.st, d_sum, s, tm, ppw);
+            }
+            else if (brute_)
                 run_batch<R, true>(S, cam, B, im.st, d_sum, s, tm);
             else
                 run_batch<R, false>(S, cam, B, im.st, d_sum, s, tm);

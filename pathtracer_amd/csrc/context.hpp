@@ -77,6 +77,8 @@ public:
     int64_t default_batch_paths = int64_t(1) << 23;
     // slots per wave-private queue region (multiple of 64)
     int region_slots = 512;
+    // > 0: persistent tracer, this many consecutive path ids per wave
+    int paths_per_wave = 1024;
 
     struct Geometry;
     template <class R> struct Impl;

@@ -39,9 +39,11 @@ constexpr int MAX_LIGHTS = 32;  // lights per scene when NEE terms are deferred 
 template <class R> struct DScene
 {
     int n_tris, n_mats, n_lights, n_square;
-    int brute, enable_indirect, enable_bary, pad0;
+    int brute, enable_indirect, enable_bary, n_recs;
     const R *tri_pre;          // [n_tris][12] in intersector order: p1, p1-p2, p1-p3, cofactors
-    const float *tri_pf;       // [n_tris][16] f32 prefilter records (all-triangles intersector)
+    const float *tri_pq;       // [n_recs][32] f32 plane records (all-triangles intersector)
+    const int32_t *rec_tri;    // [64] candidate bit -> triangle, -1: none
+    const int32_t *tri_rec;    // [n_tris] triangle -> plane record
     const int32_t *tri_face;   // intersector order -> face id
     const float *verts;        // [n_faces][9]  by face id
     const float *normals;      // [n_faces][9]
@@ -96,6 +98,7 @@ template <class R> struct DState
     R *stack_d;                   // [depth][3][N] by pid
     R *stack_c;                   // [depth][3][N] by pid
     uint32_t *path_state;         // [N] by pid: (len << 16) | (tail material + 1)
+    R *stack;                     // [N][depth][6] by pid: direct rgb, coefficient rgb (persistent tracer)
     // deferred NEE (only when the scene has square lights).  The per-light terms stay at the
     // queue slot of the path; only the list of slots that need visibility tests is packed.
     uint32_t *nee_idx;            // [N] region-wise dense list of slots with pending tests
@@ -127,86 +130,110 @@ template <class R> __device__ __forceinline__ R box_entry(const float *lo, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// two-phase all-triangles intersector (f64).  Phase 1 walks every triangle in a wave-uniform loop
-// (records read through the scalar cache) with a division-free f32 Moller-Trumbore test whose
-// rounding error is bounded per triangle, and only REJECTS what the exact test is certain to reject
-// (or to ignore); the survivors form a per-lane bit mask.  Phase 2 runs the exact f64 test of the
-// reference on each lane's own candidates (triangle data from LDS), in ascending face order, so
-// decisions, distances and tie-breaking are bit-identical to testing all triangles exactly.
+// two-phase all-triangles intersector.  Phase 1 walks a short list of f32 "plane records" in a
+// wave-uniform loop (records read through the scalar cache).  A record is the supporting plane of
+// one triangle A = (P0, P0 + e1, P0 + e2), or of two exactly coplanar triangles A and B that share
+// the edge (P0 + e1, P0 + e2) -- the two halves of a quad face.  The test intersects the ray with
+// the plane, expresses the point in the (e1, e2) basis and only REJECTS what the exact test is
+// certain to reject, using forward error bounds that grow with 1 / cos^2 of the incidence angle;
+// survivors form a per-lane bit mask (bit 2r: triangle A of record r, bit 2r + 1: triangle B).
+// Phase 2 runs the exact test of the reference (in R) on each lane's own candidates, triangle data
+// from LDS, with the reference's tie rule (equal distance -> lowest face id), so hits, distances
+// and tie-breaking are identical to testing every triangle exactly.
 //
-// Prefilter record (16 floats): p1[3], e1 = p2-p1 [3], e2 = p3-p1 [3], then with K = 128 * 2^-24:
-//   cu = K max|e2|, cv = K max|e1|, ct = K max|e1| max|e2|, cdet = K max|e1| max|e2|, max|p1|,
-//   1.001 (cu + cv), 1.001 cdet.
-// With T = max|o| + max|p1| the f32 numerators are off by at most cu T, cv T, ct T and the
-// determinant by cdet (|d| <= 1), from a forward error analysis of the fused dot/cross products
-// including the rounding of the inputs to f32 (each bound < 66 * 2^-24 * magnitudes).
+// Record (32 floats):
+//   0-2 unit normal n, 3 c = n.P0,
+//   4-6 a, 7 a.P0   (u = a.X - a.P0),   8-10 b, 11 b.P0   (v = b.X - b.P0),
+//   12,13 centre and half width of the u range, 14,15 of the v range (A alone: [0,1]; with B: the
+//   box around both), 16,17 Eu, Eu0, 18,19 Ev, Ev0, 20 Et, 21 |c|, 22 0 (with B) or +inf (A alone).
+// With r = 1 / |n.d|, To = max|o| and W = (1.75 To + |c|) r^2 the computed t, u, v are within
+// Et W, Eu W + Eu0, Ev W + Ev0 of their exact values (Eu = 64 eps |a|_1, Eu0 = 16 eps |a.P0|,
+// Et = 32 eps; first-order bounds are 13, 24 and 5 eps, including the rounding of the ray and of the
+// record to f32).
 // ---------------------------------------------------------------------------------------------
-constexpr int PF_STRIDE = 16;
-constexpr int BRUTE_MAX_TRIS = 64; // candidate mask is one 64-bit word
+constexpr int PQ_STRIDE = 32;
+constexpr int BRUTE_MAX_TRIS = 64; // candidate mask is one 64-bit word ...
+constexpr int BRUTE_MAX_RECS = 32; // ... of two bits per record
 
-// LDS scratch of the intersecting kernels: the per-lane BVH stacks, or (all-triangles intersector)
-// a copy of the f64 triangle table that every lane indexes with its own candidate
-constexpr int LDS_WORDS_BRUTE = BRUTE_MAX_TRIS * 12 * 2;
+// LDS tables of the all-triangles intersector (one copy per workgroup)
+template <class R> struct BruteLds
+{
+    R tri[BRUTE_MAX_TRIS * 12];         // exact-test records, by triangle
+    int rec_tri[2 * BRUTE_MAX_RECS];    // mask bit -> triangle (-1: none)
+    int tri_rec[BRUTE_MAX_TRIS];        // triangle -> plane record
+    float rec_n[BRUTE_MAX_RECS * 4];    // unit normals of the plane records
+};
+constexpr int LDS_WORDS_BRUTE = int(sizeof(BruteLds<double>) / 4);
+
+// LDS scratch of the intersecting kernels: the tables above, or the per-lane BVH stacks
 template <class R, bool BRUTE> __device__ __forceinline__ int *intersector_scratch(const DScene<R> &S, int *lds)
 {
     if (BRUTE)
     {
-        if constexpr (sizeof(R) == 8)
-        {
-            double *dst = reinterpret_cast<double *>(lds);
-            for (int k = threadIdx.x; k < S.n_tris * 12; k += BLOCK)
-                dst[k] = S.tri_pre[k];
-            __syncthreads();
-        }
-        return lds; // shared table: same pointer for every lane
+        BruteLds<R> *L = reinterpret_cast<BruteLds<R> *>(lds);
+        for (int k = threadIdx.x; k < S.n_tris * 12; k += BLOCK)
+            L->tri[k] = S.tri_pre[k];
+        for (int k = threadIdx.x; k < 2 * BRUTE_MAX_RECS; k += BLOCK)
+            L->rec_tri[k] = S.rec_tri[k];
+        for (int k = threadIdx.x; k < S.n_tris; k += BLOCK)
+            L->tri_rec[k] = S.tri_rec[k];
+        for (int k = threadIdx.x; k < S.n_recs * 4; k += BLOCK)
+            L->rec_n[k] = S.tri_pq[(k >> 2) * PQ_STRIDE + (k & 3)];
+        __syncthreads();
+        return lds; // shared tables: same pointer for every lane
     }
     return lds + threadIdx.x; // BVH: stack slot [level][lane]
 }
 
-__device__ __forceinline__ float flip(float x, uint32_t sbit) { return __uint_as_float(__float_as_uint(x) ^ sbit); }
-
-// skip: intersector-order index of the triangle the ray starts on (-1: none).  Hits of that
-// triangle are at distance ~0 and ignored by the exact test unless the ray grazes its plane, so it
-// is dropped only when the determinant is far from zero.
-__device__ __forceinline__ unsigned long long prefilter_mask(const float *__restrict__ PF, int n_tris, V3<double> o, V3<double> d,
-                                                             float tmin, float tmax, int skip)
+template <class R>
+__device__ __forceinline__ unsigned long long prefilter_mask(const float *__restrict__ PQ, int n_recs, V3<R> o, V3<R> d, float tmin,
+                                                             float tmax)
 {
 #pragma clang fp contract(fast) // rounding differences are inside the error bounds of the records
     const float ox = float(o.x), oy = float(o.y), oz = float(o.z);
     const float dx = float(d.x), dy = float(d.y), dz = float(d.z);
-    const float To = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
+    const float To = 1.75f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
     uint32_t mlo = 0, mhi = 0;
-    for (int f = 0; f < n_tris; f++)
+    for (int r = 0; r < n_recs; r++)
     {
-        const float *__restrict__ P = PF + f * PF_STRIDE;
-        const float tx = ox - P[0], ty = oy - P[1], tz = oz - P[2];
-        const float e1x = P[3], e1y = P[4], e1z = P[5], e2x = P[6], e2y = P[7], e2z = P[8];
-        const float px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;
-        const float det = e1x * px + e1y * py + e1z * pz;
-        const float nu = tx * px + ty * py + tz * pz;
-        const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
-        const float nv = dx * qx + dy * qy + dz * qz;
-        const float nt = e2x * qx + e2y * qy + e2z * qz;
-        const uint32_t sbit = __float_as_uint(det) & 0x80000000u;
-        const float A = fabsf(det);
-        const float T = To + P[13];
-        const float Ed = P[12];
-        const float su = flip(nu, sbit), sv = flip(nv, sbit), st = flip(nt, sbit);
-        // barycentrics: min(beta, gamma, alpha) numerators, each lifted by its error bound
-        const float ub = fmaf(P[9], T, su), vb = fmaf(P[10], T, sv);
-        const float ab = fmaf(P[14], T, (A - su - sv) + P[15]); // P[14] = 1.001 (cu + cv), P[15] = 1.001 cdet
-        const float slack = 1e-6f * (A + Ed);
-        const bool rej = (fminf(fminf(ub, vb), ab) < -slack) | (fmaf(P[11], T, st) < tmin * (A - Ed)) |
-                         (fmaf(-P[11], T, st) > tmax * (A + Ed));
-        bool keep = !((A > Ed) & rej);
-        if (f == skip && A > 1024.0f * Ed)
-            keep = false;
-        if (f < 32)
-            mlo |= keep ? (1u << f) : 0u;
+        const float *__restrict__ P = PQ + r * PQ_STRIDE;
+        const float nd = P[0] * dx + P[1] * dy + P[2] * dz;
+        const float no = P[3] - (P[0] * ox + P[1] * oy + P[2] * oz);
+        const float rr = __builtin_amdgcn_rcpf(nd);
+        const float t = no * rr;
+        const float W = (To + P[21]) * (rr * rr);
+        const float X = fmaf(t, dx, ox), Y = fmaf(t, dy, oy), Z = fmaf(t, dz, oz);
+        const float u = fmaf(P[4], X, fmaf(P[5], Y, fmaf(P[6], Z, -P[7])));
+        const float v = fmaf(P[8], X, fmaf(P[9], Y, fmaf(P[10], Z, -P[11])));
+        const float eu = fmaf(P[16], W, P[17]), ev = fmaf(P[18], W, P[19]), et = P[20] * W;
+        // all comparisons are false on NaN / infinity soup, which keeps the candidate
+        const bool out = (fabsf(u - P[12]) > P[13] + eu) || (fabsf(v - P[14]) > P[15] + ev) || (t + et < tmin) || (t - et > tmax);
+        const float s = (u + v) - 1.0f, es = eu + ev;
+        const bool ka = !(out || s > es);
+        const bool kb = !(out || s + es < P[22]);
+        const uint32_t bits = (ka ? 1u : 0u) | (kb ? 2u : 0u);
+        if (r < 16)
+            mlo |= bits << (2 * r);
         else
-            mhi |= keep ? (1u << (f - 32)) : 0u;
+            mhi |= bits << (2 * r - 32);
     }
     return ((unsigned long long)mhi << 32) | mlo;
+}
+
+// A ray that starts on triangle `own` meets the plane of that triangle (and of its coplanar
+// partner) at distance ~0, which the exact test ignores unless the ray grazes the plane: the
+// candidates of that record are dropped when |n.d| is far from zero.
+template <class R>
+__device__ __forceinline__ unsigned long long drop_own_plane(unsigned long long mask, const BruteLds<R> *L, int own, V3<R> d)
+{
+    if (own >= 0)
+    {
+        const int r = L->tri_rec[own];
+        const float nd = L->rec_n[r * 4] * float(d.x) + L->rec_n[r * 4 + 1] * float(d.y) + L->rec_n[r * 4 + 2] * float(d.z);
+        if (fabsf(nd) > 1e-3f)
+            mask &= ~(3ull << (2 * r));
+    }
+    return mask;
 }
 
 // closest hit.  Returns the intersector-order triangle index (or -1) and the hit point.
@@ -219,39 +246,21 @@ __device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d,
     const R self_eps = Consts<R>::self_eps;
     if (BRUTE)
     {
-        if constexpr (sizeof(R) == 8)
+        const BruteLds<R> *L = reinterpret_cast<const BruteLds<R> *>(stk);
+        unsigned long long mask = prefilter_mask(S.tri_pq, S.n_recs, o, d, float(self_eps) * 0.9f, __builtin_inff());
+        mask = drop_own_plane(mask, L, skip, d);
+        while (mask)
         {
-            // stk points at this lane's view of the LDS copy of tri_pre (see load_tris_to_lds)
-            const double *lds_tri = reinterpret_cast<const double *>(stk);
-            unsigned long long mask = prefilter_mask(S.tri_pf, S.n_tris, o, d, 9e-7f, __builtin_inff(), skip);
-            while (mask)
-            {
-                const int f = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                R t;
-                if (tri_test(lds_tri + f * 12, o, d, t))
-                {
-                    V3<R> p = o + t * d;
-                    R dist = norm(p - o);
-                    if (dist < best && dist > self_eps)
-                    {
-                        best = dist;
-                        target = f;
-                        pt = p;
-                    }
-                }
-            }
-            return target;
-        }
-        const R *__restrict__ T = S.tri_pre;
-        for (int f = 0; f < S.n_tris; f++)
-        {
+            const int bit = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int f = L->rec_tri[bit];
             R t;
-            if (tri_test(T + f * 12, o, d, t))
+            if (f >= 0 && tri_test(L->tri + f * 12, o, d, t))
             {
                 V3<R> p = o + t * d;
                 R dist = norm(p - o);
-                if (dist < best && dist > self_eps)
+                // intersector order = face order here, so the triangle index breaks ties
+                if (dist > self_eps && (dist < best || (dist == best && f < target)))
                 {
                     best = dist;
                     target = f;
@@ -334,29 +343,21 @@ template <class R, bool BRUTE> __device__ __forceinline__ bool visible(const DSc
     V3<R> dir = normalized(p2 - p1);
     if (BRUTE)
     {
-        if constexpr (sizeof(R) == 8)
-        {
-            const double *lds_tri = reinterpret_cast<const double *>(stk);
-            // blockers have self_eps < t < dist - self_eps: drop what surely lies outside (0.9e-6, dist)
-            const float far = float(dist) * 1.00001f + 1e-30f;
-            unsigned long long mask = prefilter_mask(S.tri_pf, S.n_tris, p1, dir, 9e-7f, far, skip);
-            bool blocked = false;
-            while (mask && !blocked)
-            {
-                const int f = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                R t;
-                if (tri_test(lds_tri + f * 12, p1, dir, t) && t < dist - self_eps && t > self_eps)
-                    blocked = true;
-            }
-            return !blocked;
-        }
-        const R *__restrict__ T = S.tri_pre;
+        const BruteLds<R> *L = reinterpret_cast<const BruteLds<R> *>(stk);
+        // blockers have self_eps < t < dist - self_eps: drop what surely lies outside (0.9 self_eps, dist)
+        const float far = float(dist) * 1.00001f + 1e-30f;
+        unsigned long long mask = prefilter_mask(S.tri_pq, S.n_recs, p1, dir, float(self_eps) * 0.9f, far);
+        // p2 lies on triangle `skip`: as seen from p1 its plane is met at distance ~dist, which is
+        // not a blocker either
+        mask = drop_own_plane(mask, L, skip, dir);
         bool blocked = false;
-        for (int f = 0; f < S.n_tris; f++)
+        while (mask && !blocked)
         {
+            const int bit = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int f = L->rec_tri[bit];
             R t;
-            if (tri_test(T + f * 12, p1, dir, t) && t < dist - self_eps && t > self_eps)
+            if (f >= 0 && tri_test(L->tri + f * 12, p1, dir, t) && t < dist - self_eps && t > self_eps)
                 blocked = true;
         }
         return !blocked;
@@ -568,7 +569,7 @@ __device__ __forceinline__ uint64_t path_rng_key(const DBatch &B, uint32_t pid, 
 // loads at the top of an iteration (the queue slot, prefetched one iteration ahead) and reads the
 // small tables -- materials, lights, per-triangle normals -- from LDS copies (LDS has its own
 // counter).  TAB: materials and lights fit LDS; NRM: the per-triangle normal table fits too.
-constexpr int SHADE_LDS_MATS = 64, SHADE_LDS_LIGHTS = 32, SHADE_LDS_TRIS = 64;
+constexpr int SHADE_LDS_MATS = 48, SHADE_LDS_LIGHTS = 32, SHADE_LDS_TRIS = 64;
 
 template <class R, bool TAB, bool NRM>
 __global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S, DBatch B, DState<R> st, int bounce)
@@ -821,6 +822,244 @@ template <class R, bool BRUTE> __global__ void __launch_bounds__(BLOCK) k_shadow
         tests += __shfl_down(tests, off, 64);
     if (lane == 0 && tests)
         st.wave_stats[g * 4 + 1] += tests; // the wave owns its row: plain read-modify-write
+}
+
+// ---------------------------------------------------------------------------------------------
+// persistent tracer: every LANE carries one path in registers from its camera ray to its end --
+// closest hit, termination rules, shading normal, next direction, NEE with its visibility tests --
+// and then starts the next path of its wave's range (path regeneration).  No ray ever goes through
+// memory: the only global traffic is one 6-scalar stack record per shaded segment and one state
+// word per path.  Wave g owns the path ids [g * paths_per_wave, (g + 1) * paths_per_wave); every
+// wave leaves the loop once its range is used up and its 64 lanes are idle.
+// ---------------------------------------------------------------------------------------------
+template <class R, bool BRUTE, bool TAB, bool NRM>
+__global__ void __launch_bounds__(BLOCK) k_trace(DScene<R> S, DCamera cam, DBatch B, DState<R> st, int paths_per_wave)
+{
+    __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : BVH_STACK * BLOCK];
+    __shared__ R lds_mats[TAB ? SHADE_LDS_MATS * MAT_STRIDE : 1];
+    __shared__ R lds_lights[TAB ? SHADE_LDS_LIGHTS * LIGHT_STRIDE : 1];
+    __shared__ R lds_nrm[NRM ? SHADE_LDS_TRIS * 4 : 1];
+    __shared__ int lds_tmat[NRM ? SHADE_LDS_TRIS : 1];
+    if (TAB)
+    {
+        for (int k = threadIdx.x; k < S.n_mats * MAT_STRIDE; k += BLOCK)
+            lds_mats[k] = S.mats[k];
+        for (int k = threadIdx.x; k < S.n_lights * LIGHT_STRIDE; k += BLOCK)
+            lds_lights[k] = S.lights[k];
+    }
+    if (NRM)
+    {
+        for (int k = threadIdx.x; k < S.n_tris * 4; k += BLOCK)
+            lds_nrm[k] = S.tri_nrm[k];
+        for (int k = threadIdx.x; k < S.n_tris; k += BLOCK)
+            lds_tmat[k] = S.tri_mat[k];
+    }
+    int *stk = intersector_scratch<R, BRUTE>(S, lds_raw);
+    __syncthreads(); // the only barrier: from here on the waves of the workgroup are independent
+    const int g = global_wave(), lane = lane_id();
+    if (g >= st.n_regions)
+        return;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t n_paths = uint32_t(B.n_paths);
+    const int64_t first = (int64_t)g * paths_per_wave;
+    uint32_t next = uint32_t(first < (int64_t)n_paths ? first : (int64_t)n_paths);
+    const uint32_t end = uint32_t(first + paths_per_wave < (int64_t)n_paths ? first + paths_per_wave : (int64_t)n_paths);
+    const uint32_t n_pix = uint32_t(B.n_pix), n_cols = uint32_t(B.n_cols);
+    const int depth = B.depth;
+
+    bool alive = false;
+    V3<R> o = {R(0), R(0), R(0)}, d = {R(0), R(0), R(0)};
+    uint32_t pid = 0, sample = 0;
+    int bounce = 0, prim = -1;
+    uint64_t key = 0;
+    uint32_t n_seg = 0, n_tests = 0, n_iter = 0;
+
+    for (;;)
+    {
+        // ---- idle lanes take the next path ids of the wave's range ------------------------------
+        const unsigned long long idle = __ballot(!alive);
+        if (!alive)
+        {
+            const uint32_t cand = next + uint32_t(__popcll(idle & lt_mask));
+            if (cand < end)
+            {
+                pid = cand;
+                const uint32_t pix = pid % n_pix, s_local = pid / n_pix;
+                const int lr = B.row0 + int(pix / n_cols), col = B.col0 + int(pix % n_cols);
+                const int row = local_row_to_image_row(B, lr);
+                primary_ray<R>(cam, col, row, o, d);
+                key = rng_pixel_key(B.seed, uint32_t(row) * uint32_t(B.image_width) + uint32_t(col));
+                sample = uint32_t(B.sample0) + s_local;
+                bounce = 0, prim = -1;
+                alive = true;
+            }
+        }
+        {
+            const uint32_t taken = uint32_t(__popcll(idle));
+            next = end - next < taken ? end : next + taken;
+        }
+        if (__ballot(alive) == 0ull)
+            break; // range used up and every lane idle
+        n_iter++;
+        if (!alive)
+            continue;
+        n_seg++;
+
+        // ---- closest hit and the termination rules (miss / no material -> tail 0; emitter -> Ka) --
+        V3<R> p = {R(0), R(0), R(0)};
+        const int hit_k = closest_hit<R, BRUTE>(S, o, d, p, stk, prim);
+        int mat_id = -1;
+        if (hit_k >= 0)
+            mat_id = NRM ? lds_tmat[hit_k] : S.tri_mat[hit_k];
+        const int mrow = (mat_id < 0 ? 0 : mat_id) * MAT_STRIDE;
+        const R *m; // the address space (LDS or global) is fixed at compile time
+        if constexpr (TAB)
+            m = lds_mats + mrow;
+        else
+            m = S.mats + mrow;
+        alive = false;
+        if (mat_id < 0)
+        {
+            st.path_state[pid] = uint32_t(bounce) << 16;
+            continue;
+        }
+        if (m[13] != R(0))
+        {
+            st.path_state[pid] = (uint32_t(bounce) << 16) | uint32_t(mat_id + 1);
+            continue;
+        }
+
+        // ---- shading normal: precomputed per triangle when it is flat (its three vertex normals are
+        // equal) or when barycentric normals are off; else interpolated ---------------------------
+        const V3<R> wo = -d;
+        R fn0, fn1, fn2, fn3;
+        if (NRM)
+            fn0 = lds_nrm[hit_k * 4], fn1 = lds_nrm[hit_k * 4 + 1], fn2 = lds_nrm[hit_k * 4 + 2], fn3 = lds_nrm[hit_k * 4 + 3];
+        else
+        {
+            const R *__restrict__ fn = S.tri_nrm + (size_t)hit_k * 4;
+            fn0 = fn[0], fn1 = fn[1], fn2 = fn[2], fn3 = fn[3];
+        }
+        V3<R> nrm = {fn0, fn1, fn2};
+        if (fn3 == R(0))
+        {
+            const int face = S.tri_face[hit_k];
+            const float *__restrict__ vp = S.verts + (size_t)face * 9;
+            const float *__restrict__ np = S.normals + (size_t)face * 9;
+            V3<R> a = {R(vp[0]), R(vp[1]), R(vp[2])}, b = {R(vp[3]), R(vp[4]), R(vp[5])}, c = {R(vp[6]), R(vp[7]), R(vp[8])};
+            V3<R> w = barycentric(p, a, b, c);
+            V3<R> acc = w.x * V3<R>{R(np[0]), R(np[1]), R(np[2])};
+            acc = acc + w.y * V3<R>{R(np[3]), R(np[4]), R(np[5])};
+            acc = acc + w.z * V3<R>{R(np[6]), R(np[7]), R(np[8])};
+            nrm = fast_normalized(acc);
+        }
+
+        // ---- next direction and indirect coefficient ---------------------------------------------
+        V3<R> coef = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
+        if (S.enable_indirect)
+        {
+            const R x1 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 0);
+            const R x2 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 1);
+            bxdf_sample(m, nrm, wo, x1, x2, wi, coef);
+        }
+
+        // ---- NEE over all lights, in order, each square-light sample with its visibility test ----
+        V3<R> direct = {R(0), R(0), R(0)};
+        for (int l = 0; l < S.n_lights; l++)
+        {
+            const R *L;
+            if constexpr (TAB)
+                L = lds_lights + l * LIGHT_STRIDE;
+            else
+                L = S.lights + (size_t)l * LIGHT_STRIDE;
+            V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
+            R pdf;
+            const R x1 = rng_draw<R>(key, sample, bounce, 4 * l + 0);
+            const R x2 = rng_draw<R>(key, sample, bounce, 4 * l + 1);
+            const bool square = L[0] == R(0);
+            if (square)
+                pdf = square_light_sample(L, p, x1, x2, ro, rd);
+            else
+                pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bounce, 4 * l + 2), ro, rd);
+            if (pdf < R(1e-10))
+                continue;
+            const R cn = dot(nrm, -rd);
+            if (cn < R(0))
+                continue;
+            const V3<R> f = bxdf_eval(m, rd, wo, nrm);
+            const R w = cn / pdf;
+            const V3<R> term = {(L[1] * w) * f.x, (L[2] * w) * f.y, (L[3] * w) * f.z};
+            if (square)
+            {
+                n_tests++;
+                if (!visible<R, BRUTE>(S, ro, p, stk, hit_k))
+                    continue;
+            }
+            direct = direct + term;
+        }
+
+        // ---- one stack record per shaded segment --------------------------------------------------
+        R *rec = st.stack + ((size_t)pid * depth + bounce) * 6;
+        rec[0] = direct.x, rec[1] = direct.y, rec[2] = direct.z;
+        rec[3] = coef.x, rec[4] = coef.y, rec[5] = coef.z;
+        if (S.enable_indirect && bounce + 1 < depth)
+        {
+            o = p, d = wi, prim = hit_k;
+            bounce++;
+            alive = true;
+        }
+        else
+            st.path_state[pid] = uint32_t(bounce + 1) << 16;
+    }
+    // per-wave statistics (the wave owns its row)
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        n_seg += __shfl_down(n_seg, off, 64);
+        n_tests += __shfl_down(n_tests, off, 64);
+    }
+    if (lane == 0)
+    {
+        st.wave_stats[g * 4 + 0] = n_seg;
+        st.wave_stats[g * 4 + 1] = n_tests;
+        st.wave_stats[g * 4 + 2] = n_iter;
+        st.wave_stats[g * 4 + 3] = 0;
+    }
+}
+
+// one thread per path: folds the path's stack records back to front with the per-bounce max-clamp;
+// the per-sample result goes to stack_d[0][.][pid]
+template <class R> __global__ void __launch_bounds__(BLOCK) k_resolve_records(DScene<R> S, DBatch B, DState<R> st)
+{
+    const int64_t pid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (pid >= B.n_paths)
+        return;
+    const int64_t N = st.N;
+    const uint32_t ps = st.path_state[pid];
+    const int len = int(ps >> 16), tm = int(ps & 0xffff);
+    R fr = R(0), fg = R(0), fb = R(0);
+    if (tm)
+    {
+        const R *m = S.mats + (size_t)(tm - 1) * MAT_STRIDE;
+        fr = m[0], fg = m[1], fb = m[2];
+    }
+    const R *rec = st.stack + (size_t)pid * B.depth * 6;
+    for (int i = len - 1; i >= 0; i--)
+    {
+        const R *q = rec + i * 6;
+        fr = q[0] + q[3] * fr;
+        fg = q[1] + q[4] * fg;
+        fb = q[2] + q[5] * fb;
+        R mx = fr;
+        if (fg > mx)
+            mx = fg;
+        if (fb > mx)
+            mx = fb;
+        if (R(0) > mx)
+            mx = R(0);
+        if (mx > R(1))
+            fr /= mx, fg /= mx, fb /= mx;
+    }
+    st.stack_d[pid] = fr, st.stack_d[N + pid] = fg, st.stack_d[2 * N + pid] = fb;
 }
 
 // one thread per path: folds its (direct, coefficient) stack back to front with the per-bounce

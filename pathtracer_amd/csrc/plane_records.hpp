@@ -1,0 +1,25 @@
+// f32 plane records of the all-triangles intersector: one record per triangle, or per pair of
+// exactly coplanar triangles that share an edge (the two halves of a quad face).  See kernels.hpp
+// for the record layout and the device-side test.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace ptx
+{
+
+constexpr int PLANE_REC_STRIDE = 32;
+
+struct PlaneRecords
+{
+    std::vector<float> rec;        // [n_recs][32]
+    std::vector<int32_t> rec_tri;  // [64] candidate bit (2 r: triangle A, 2 r + 1: triangle B) -> triangle, -1: none
+    std::vector<int32_t> tri_rec;  // [n_tris] triangle -> record
+    int n_recs = 0;
+    int n_pairs = 0;
+};
+
+// verts: [n_tris][9] float positions by face id.  Triangles stay in face order.
+void build_plane_records(const float *verts, int n_tris, PlaneRecords &out);
+
+} // namespace ptx
