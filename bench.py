@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mpaths/s on the Cornell box at 1024 x 1024, 256 spp per GPU.
 
-One "step" = one full pass of the hot path over the workload: camera rays, 15 bounces of
-extend / shade / shadow, resolve -- i.e. cPathTracer::Process of the reference for
+One "step" = one full pass of the hot path over the workload: camera rays, up to 15 bounces of
+closest hit / shading / NEE with visibility per path, resolve, accumulate -- i.e.
+cPathTracer::Process of the reference for
 config/cbox.conf at 1024 x 1024 x 256 spp (BASELINE.json configs[1]).  With N GPUs every rank
 renders its own range of 256 samples of the same image (weak scaling: 256 * N spp in total) and the
 per-pixel sums are reduced onto rank 0 over RCCL inside the timed region.
@@ -25,26 +26,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, spec
-F64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector FP64 (FMA counted as 2 flop), spec
-F32_VALU_PEAK_TFLOPS = 157.3
+N_SIMD = 1024                # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4              # peak engine clock
+VALU_ISSUE_PEAK = N_SIMD * CLOCK_GHZ / 4.0   # G wave64-instructions/s: one per SIMD every 4 cycles
 
 
-def algorithmic_bytes(mode, n_lights, n_square):
-    """Bytes each kernel must move per unit of work with ideal caching (scene tables excluded:
-    the 26-triangle scene is read through the scalar cache).  R = size of the scalar type."""
+def algorithmic_bytes(mode, st, n_pix_touched):
+    """HBM bytes each kernel must move for the work of one step (scene tables excluded: they are a
+    few KB read through the scalar cache / LDS).  R = size of the scalar type.
+      k_trace ...... one 6-scalar (direct, coefficient) record per shaded segment + one state word per path;
+                     rays, hits and NEE samples never leave the registers
+      k_resolve .... reads those records and state words, writes 3 scalars per path
+      k_accumulate . reads 3 scalars per path, reads + writes the f64 rgb sum of every pixel it touches"""
     R = 8 if mode == "f64" else 4
-    deferred = n_square > 0
-    extend = 6 * R + 4 + 3 * R                      # read ray o,d; write prim id + hit point
-    shade = (4 + 4 + 3 * R + 3 * R + 72             # pid, prim, hit point, ray d, 3 pos + 3 normals (f32)
-             + 3 * R                                # push coefficient
-             + (n_lights * 6 * R + 8 if deferred else 3 * R)   # per-light terms + sample points | direct
-             + 6 * R + 4)                           # next ray + pid
-    shadow = 4 + 4 + 4 + 3 * R + n_lights * 6 * R + 3 * R      # idx, pid, mask, point, terms, write direct
-    return dict(extend=extend, shade=shade, shadow=shadow)
+    rec, paths = st["records"], st["paths"]
+    return {"trace": rec * 6 * R + paths * 4,
+            "resolve": rec * 6 * R + paths * (4 + 3 * R),
+            "accumulate": paths * 3 * R + n_pix_touched * 48}
 
 
-def tri_test_flops():
-    return 60.0  # r (3), col1 x d (9), det (5), 1/det (1), beta (8), d x col0 and scale (12), gamma (5), t (8), alpha (2), compares (7)
+def valu_calibration(mode):
+    """VALU instructions per 64-lane bounce iteration of k_trace, from the committed PMC profile
+    (SQ_INSTS_VALU / wave iterations of the same workload); None when the profile is absent."""
+    path = os.path.join(ROOT, "profiles", "valu_calibration.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(mode)
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -123,27 +132,36 @@ def main():
         # on the render stream (same workload, same stream; not part of the timed region above)
         ps = step(profile=True, reduce=False)   # rank 0 only: no collective in here
         torch.cuda.synchronize()
-        classes = {"extend": ps["ms_extend"], "shade": ps["ms_shade"], "shadow": ps["ms_shadow"]}
-        dom = max(classes, key=classes.get)
-        launches = int(ps["passes"]) * info.depth
-        units = {"extend": ps["segments"], "shade": ps["segments"], "shadow": ps["shadow_rays"]}
-        ab = algorithmic_bytes(args.mode, info.n_lights, info.n_square_lights)
-        bytes_per_launch = ab[dom] * units[dom] / launches
-        avg_ms = classes[dom] / launches
+        ms = {"trace": ps["ms_trace"], "resolve": ps["ms_resolve"], "accumulate": ps["ms_accumulate"]}
+        passes = int(ps["passes"])
+        ab = algorithmic_bytes(args.mode, ps, W * H * passes)
+        dom = max(ms, key=ms.get)
+        kernels = {}
+        for k in ms:
+            gbs = ab[k] / (ms[k] * 1e-3) / 1e9 if ms[k] > 0 else 0.0
+            kernels["k_" + k] = {"ms_per_step": round(ms[k], 3), "launches_per_step": passes,
+                                 "algorithmic_bytes_per_launch": round(ab[k] / passes),
+                                 "achieved_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+        bytes_per_launch = ab[dom] / passes
+        avg_ms = ms[dom] / passes
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        tests_per_unit = info.n_tris  # all-triangles loop of the 26-triangle scene
-        flops = tri_test_flops() * tests_per_unit * units[dom] if dom != "shade" else 0.0
-        peak_t = F64_VALU_PEAK_TFLOPS if args.mode == "f64" else F32_VALU_PEAK_TFLOPS
-        valu_ach = flops / (classes[dom] * 1e-3) / 1e12 if classes[dom] > 0 else 0.0
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "bytes_per_launch": round(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5),
-                    "launches_per_step": launches,
-                    "note": "the all-triangles intersector is VALU-bound, see valu"}
-        valu = {"kernel": "k_" + dom, "achieved": round(valu_ach, 2), "peak": peak_t, "unit": "TFLOP/s",
-                "frac": round(valu_ach / peak_t, 4), "flop_per_tri_test": tri_test_flops(),
-                "note": "non-fused f64 ops count 1 flop each; the spec peak counts FMA as 2"}
-        kernel_ms = {k: round(v, 3) for k, v in classes.items()}
+                    "launches_per_step": passes,
+                    "note": "k_trace keeps rays, hits and light samples in registers, so its HBM traffic is two "
+                            "orders of magnitude below the bandwidth roof by construction; it is bound by vector-ALU "
+                            "issue, see valu"}
+        cal = valu_calibration(args.mode)
+        valu = None
+        if cal and ms["trace"] > 0:
+            rate = cal["valu_insts_per_wave_iteration"] * ps["wave_iterations"] / (ms["trace"] * 1e-3) / 1e9
+            valu = {"kernel": "k_trace", "achieved": round(rate, 1), "peak": VALU_ISSUE_PEAK,
+                    "unit": "G wave64 VALU instructions/s", "frac": round(rate / VALU_ISSUE_PEAK, 4),
+                    "valu_insts_per_wave_iteration": cal["valu_insts_per_wave_iteration"],
+                    "active_lane_fraction": round(ps["segments"] / (64.0 * max(ps["wave_iterations"], 1)), 4),
+                    "source": cal.get("source")}
+        kernel_ms = {k: round(v, 3) for k, v in ms.items()}
         kernel_ms["other"] = round(ps["ms_other"], 3)
 
         # the other precision, one step, for the record
@@ -170,7 +188,7 @@ def main():
                        "sharding": "sample ranges per rank + RCCL reduce(sum) of the radiance sums to rank 0"},
             "mrays_per_s": round((st["segments"] + st["shadow_rays"]) * world * args.steps / dt / 1e6, 1),
             "segments_per_path": round(st["segments"] / st["paths"], 3),
-            "roofline": roofline, "valu": valu, "kernel_ms_per_step": kernel_ms,
+            "roofline": roofline, "valu": valu, "kernels": kernels, "kernel_ms_per_step": kernel_ms,
             "other_mode": {"dtype": other_mode, "value": None if other_value is None else round(other_value, 3)},
             "cpu_baseline": cpu, "checks": checks,
         }

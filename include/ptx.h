@@ -64,7 +64,7 @@ typedef struct ptx_render_opts
     uint64_t seed;         /* RNG seed (the reference's srand(13) -> default 13)                 */
     int64_t batch_paths;   /* paths in flight per pass (<=0: library default)                    */
     int32_t accumulate;    /* != 0: add to the sums already in the output buffer                 */
-    int32_t profile;       /* != 0: time every kernel class with HIP events (slower; fills ms_*)  */
+    int32_t profile;       /* != 0: time every kernel with HIP events (fills ms_*)                 */
 } ptx_render_opts;
 
 typedef struct ptx_stats
@@ -72,11 +72,12 @@ typedef struct ptx_stats
     uint64_t paths;         /* pixel-samples traced                                              */
     uint64_t segments;      /* closest-hit rays (one per bounce of every path)                   */
     uint64_t shadow_rays;   /* visibility tests issued                                           */
-    uint64_t passes;        /* wavefront batches                                                 */
-    uint64_t wave_iterations; /* 64-lane iterations of the closest-hit kernel: segments /
+    uint64_t passes;        /* batches (tracer launches)                                         */
+    uint64_t wave_iterations; /* 64-lane bounce iterations of the tracer: segments /
                                (64 * wave_iterations) is its active-lane fraction               */
+    uint64_t records;       /* (direct, coefficient) records written = shaded segments           */
     double ms_total;        /* device time of the call, HIP events on the context's stream       */
-    double ms_extend, ms_shade, ms_shadow, ms_other; /* per-kernel-class device time (profiling
+    double ms_trace, ms_resolve, ms_accumulate, ms_other; /* per-kernel device time (profiling
                                mode only, otherwise 0)                                           */
 } ptx_stats;
 
@@ -120,9 +121,9 @@ int ptx_context_create(int32_t hip_device, ptx_context **out);
 int ptx_context_set_stream(ptx_context *, void *hip_stream);
 void ptx_context_destroy(ptx_context *);
 /* Tunables: "brute_force_limit" (scenes with at most this many triangles use the all-triangles
- * loop instead of the BVH; default 64), "default_batch_paths" (paths in flight per pass),
- * "region_slots" (slots of one wave-private queue region, multiple of 64).  Set before
- * ptx_build_accel. */
+ * intersector instead of the BVH; default and maximum 64), "default_batch_paths" (paths per
+ * tracer launch), "chunk_paths" (path ids a wave of the tracer takes from the pool at a time, 64..65536).
+ * Set before ptx_build_accel. */
 int ptx_context_set_option(ptx_context *, const char *name, int64_t value);
 int ptx_build_accel(ptx_context *, const ptx_scene *);
 /* BVH statistics of the last build: n_nodes, n_leaves, max_depth, max_leaf_tris, brute_force flag */

@@ -109,8 +109,7 @@ class Scene:
 class Context:
     """One GPU: device copy of a scene plus wavefront state."""
 
-    def __init__(self, device=0, stream=None, brute_force_limit=None, batch_paths=None, region_slots=None,
-                 paths_per_wave=None):
+    def __init__(self, device=0, stream=None, brute_force_limit=None, batch_paths=None, chunk_paths=None, trace_blocks_per_cu=None):
         L = _lib.lib()
         h = C.c_void_p()
         check(L.ptx_context_create(int(device), C.byref(h)))
@@ -122,10 +121,10 @@ class Context:
             check(L.ptx_context_set_option(self._h, b"brute_force_limit", int(brute_force_limit)))
         if batch_paths is not None:
             check(L.ptx_context_set_option(self._h, b"default_batch_paths", int(batch_paths)))
-        if region_slots is not None:
-            check(L.ptx_context_set_option(self._h, b"region_slots", int(region_slots)))
-        if paths_per_wave is not None:
-            check(L.ptx_context_set_option(self._h, b"paths_per_wave", int(paths_per_wave)))
+        if trace_blocks_per_cu is not None:
+            check(L.ptx_context_set_option(self._h, b"trace_blocks_per_cu", int(trace_blocks_per_cu)))
+        if chunk_paths is not None:
+            check(L.ptx_context_set_option(self._h, b"chunk_paths", int(chunk_paths)))
 
     def __del__(self):
         try:

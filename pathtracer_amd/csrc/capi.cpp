@@ -293,10 +293,10 @@ int ptx_context_set_option(ptx_context *c, const char *name, int64_t value)
         c->ctx->brute_force_limit = static_cast<int>(value);
     else if (n == "default_batch_paths" && value > 0)
         c->ctx->default_batch_paths = value;
-    else if (n == "region_slots" && value >= 64 && value <= (1 << 20))
-        c->ctx->region_slots = static_cast<int>(value);
-    else if (n == "paths_per_wave" && value >= 0 && value <= (1 << 24))
-        c->ctx->paths_per_wave = static_cast<int>(value);
+    else if (n == "trace_blocks_per_cu" && value >= 0 && value <= 64)
+        c->ctx->trace_blocks_per_cu = static_cast<int>(value);
+    else if (n == "chunk_paths" && value >= 64 && value <= (1 << 16))
+        c->ctx->chunk_paths = static_cast<int>(value);
     else
         return fail_arg("ptx_context_set_option: unknown option or bad value");
     return PTX_OK;
@@ -397,8 +397,9 @@ int ptx_render(ptx_context *c, const ptx_render_opts *o, double *rgb_sum, int32_
         stats->paths = st.paths, stats->segments = st.segments, stats->shadow_rays = st.shadow_rays;
         stats->passes = st.passes;
         stats->wave_iterations = st.wave_iterations;
+        stats->records = st.records;
         stats->ms_total = st.ms_total;
-        stats->ms_extend = st.ms_class[0], stats->ms_shade = st.ms_class[1], stats->ms_shadow = st.ms_class[2];
+        stats->ms_trace = st.ms_class[0], stats->ms_resolve = st.ms_class[1], stats->ms_accumulate = st.ms_class[2];
         stats->ms_other = st.ms_class[3];
     }
     PTX_CATCH

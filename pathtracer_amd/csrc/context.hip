@@ -1,10 +1,10 @@
-// Context: device scene, wavefront state and the render loop (HIP, gfx950).
+// Context: device scene, per-batch path state and the render loop (HIP, gfx950).
 //
 // Replaces cPathTracer::Init / Process / RayTracing (src/tracing/cPathTracer.cpp:20-57, 65-86,
-// 517-553 of the reference): instead of an OpenMP loop over rows that runs every path to
-// completion, paths advance one bounce at a time through three kernels (extend, shade, shadow)
-// over dense SoA queues, and a resolve kernel folds each path's (direct, coefficient) stack back
-// to front into the per-pixel sums.
+// 517-553 of the reference): instead of an OpenMP loop over rows, a batch of paths (pixels x
+// samples) is traced by one persistent kernel in which every lane carries one path at a time, a
+// resolve kernel folds each path's (direct, coefficient) records back to front, and an accumulate
+// kernel adds the per-sample results to the per-pixel sums in sample order.
 #include "context.hpp"
 #include "kernels.hpp"
 #include "plane_records.hpp"
@@ -61,18 +61,20 @@ template <class T> void upload(DeviceBuffer &b, const std::vector<T> &v, hipStre
         HIP_CHECK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
 }
 
+constexpr int MAX_TRACE_WAVES = 1 << 16; // rows of the per-wave statistics table
+
 inline unsigned blocks_for(int64_t n) { return static_cast<unsigned>(std::max<int64_t>(1, (n + BLOCK - 1) / BLOCK)); }
 
 } // namespace
 
-// per-precision device tables + wavefront state
+// per-precision device tables + per-batch path state
 template <class R> struct Context::Impl
 {
     DeviceBuffer tri_pre, mats, lights, tri_nrm;
     DeviceBuffer state_mem; // one slab carved into the DState arrays
     DState<R> st;
     int64_t capacity = 0;
-    int depth_cap = 0, lights_cap = 0;
+    int depth_cap = 0;
     bool ready = false;
 
     void build_tables(const Scene &sc, const Bvh &bvh, bool brute, hipStream_t s)
@@ -203,15 +205,13 @@ template <class R> struct Context::Impl
         ready = true;
     }
 
-    // carve the state slab for `n` paths, `depth` bounces and `n_lights` deferred-NEE lights
-    void ensure_state(int64_t n, int depth, int n_lights_deferred, int region)
+    // carve the state slab for `n` paths of up to `depth` bounces
+    void ensure_state(int64_t n, int depth)
     {
-        st.region = region;
-        if (n <= capacity && depth <= depth_cap && n_lights_deferred <= lights_cap)
+        if (n <= capacity && depth <= depth_cap)
             return;
         n = std::max(n, capacity);
         depth = std::max(depth, depth_cap);
-        n_lights_deferred = std::max(n_lights_deferred, lights_cap);
         const size_t N = static_cast<size_t>(n);
         auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
         size_t total = 0;
@@ -220,62 +220,24 @@ template <class R> struct Context::Impl
             total += align(bytes);
             return off;
         };
-        size_t o_ray[2][6], o_pid[2], o_prim[2], o_hitprim, o_hitpt[3], o_sd, o_sc, o_stk, o_ps, o_ni, o_nm, o_nc, o_cnt[2], o_ncnt, o_ws, o_stats;
-        for (int q = 0; q < 2; q++)
-        {
-            for (int c = 0; c < 6; c++)
-                o_ray[q][c] = take(N * sizeof(R));
-            o_pid[q] = take(N * 4);
-            o_prim[q] = take(N * 4);
-        }
-        o_hitprim = take(N * 4);
-        for (int c = 0; c < 3; c++)
-            o_hitpt[c] = take(N * sizeof(R));
-        o_sd = take(N * 3 * sizeof(R) * depth);
-        o_sc = take(N * 3 * sizeof(R) * depth);
-        o_stk = take(N * 6 * sizeof(R) * depth);
-        o_ps = take(N * 4);
-        o_ni = take(N * 4);
-        o_nm = take(N * 4);
-        o_nc = take(N * 3 * sizeof(R) * std::max(n_lights_deferred, 0));
-        // regions are at least 64 slots, so N / 64 + 1 bounds their number for any region size
-        const size_t max_regions = N / 64 + 1;
-        o_cnt[0] = take(max_regions * 4);
-        o_cnt[1] = take(max_regions * 4);
-        o_ncnt = take(max_regions * 4);
-        o_ws = take(max_regions * 4 * sizeof(unsigned long long));
-        o_stats = take(sizeof(unsigned long long) * 8);
+        const size_t o_stack = take(N * 6 * sizeof(R) * depth);
+        const size_t o_ps = take(N * 4);
+        const size_t o_res = take(N * 3 * sizeof(R));
+        const size_t max_waves = MAX_TRACE_WAVES;
+        const size_t o_ws = take(max_waves * 4 * sizeof(unsigned long long));
+        const size_t o_stats = take(sizeof(unsigned long long) * 8);
+        const size_t o_pool = take(sizeof(unsigned int));
         state_mem.alloc(total);
         char *base = static_cast<char *>(state_mem.p);
-        for (int q = 0; q < 2; q++)
-        {
-            for (int c = 0; c < 3; c++)
-            {
-                st.ray_o[q][c] = reinterpret_cast<R *>(base + o_ray[q][c]);
-                st.ray_d[q][c] = reinterpret_cast<R *>(base + o_ray[q][3 + c]);
-            }
-            st.q_pid[q] = reinterpret_cast<uint32_t *>(base + o_pid[q]);
-            st.q_prim[q] = reinterpret_cast<int32_t *>(base + o_prim[q]);
-        }
-        st.hit_prim = reinterpret_cast<uint32_t *>(base + o_hitprim);
-        for (int c = 0; c < 3; c++)
-            st.hit_pt[c] = reinterpret_cast<R *>(base + o_hitpt[c]);
-        st.stack_d = reinterpret_cast<R *>(base + o_sd);
-        st.stack_c = reinterpret_cast<R *>(base + o_sc);
+        st.stack = reinterpret_cast<R *>(base + o_stack);
         st.path_state = reinterpret_cast<uint32_t *>(base + o_ps);
-        st.stack = reinterpret_cast<R *>(base + o_stk);
-        st.nee_idx = reinterpret_cast<uint32_t *>(base + o_ni);
-        st.nee_mask = reinterpret_cast<uint32_t *>(base + o_nm);
-        st.nee_c = reinterpret_cast<R *>(base + o_nc);
-        st.cnt[0] = reinterpret_cast<uint32_t *>(base + o_cnt[0]);
-        st.cnt[1] = reinterpret_cast<uint32_t *>(base + o_cnt[1]);
-        st.nee_cnt = reinterpret_cast<uint32_t *>(base + o_ncnt);
+        st.result = reinterpret_cast<R *>(base + o_res);
         st.wave_stats = reinterpret_cast<unsigned long long *>(base + o_ws);
         st.stats = reinterpret_cast<unsigned long long *>(base + o_stats);
+        st.pool = reinterpret_cast<unsigned int *>(base + o_pool);
         st.N = n;
         capacity = n;
         depth_cap = depth;
-        lights_cap = n_lights_deferred;
     }
 };
 
@@ -296,6 +258,9 @@ Context::Context(int device) : device_(device)
     if (device < 0 || device >= count)
         throw std::runtime_error("arg: hip_device out of range");
     HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    n_cus_ = std::max(prop.multiProcessorCount, 1);
     f64_ = new Impl<double>();
     f32_ = new Impl<float>();
 }
@@ -335,14 +300,10 @@ void Context::build_accel(const Scene &sc)
     build_bvh(sc.verts.data(), sc.n_tris(), bvh_, 4);
     if (!brute_ && bvh_.max_depth + 2 > BVH_STACK)
         throw std::runtime_error("state: BVH deeper than the traversal stack");
-    if (sc.n_square_lights() > 0 && static_cast<int>(sc.lights.size()) > MAX_LIGHTS)
-        throw std::runtime_error("arg: at most 32 lights are supported when square lights are present");
     if (static_cast<int>(sc.mats.size()) > MAX_MATS)
-        throw std::runtime_error("arg: at most 4094 materials are supported");
-    if (sc.n_tris() > MAX_TRIS)
-        throw std::runtime_error("arg: at most 1048574 triangles are supported");
-    if (sc.depth > 4095)
-        throw std::runtime_error("arg: Depth above 4095 is not supported");
+        throw std::runtime_error("arg: at most 65534 materials are supported");
+    if (sc.depth > 65535)
+        throw std::runtime_error("arg: Depth above 65535 is not supported");
     delete geo_;
     geo_ = new Geometry();
     std::vector<int32_t> face(std::max(sc.n_tris(), 1), 0);
@@ -502,78 +463,50 @@ void Context::vistest(const double *p1, const double *p2, int64_t n, int32_t *vi
 // ------------------------------------------------------------------------------------------------
 // render loop
 // ------------------------------------------------------------------------------------------------
-template <class R, bool BRUTE>
-static void run_batch(const DScene<R> &S, const DCamera &cam, const DBatch &B, DState<R> &st, double *sum, hipStream_t s,
-                      RenderTimers *tm)
+// launches the tracer with just enough workgroups to fill the device (they are persistent: every
+// wave keeps taking path ids from the pool until it is empty)
+template <class K> static int persistent_blocks(K kernel, int n_cus, int64_t n_paths, int blocks_per_cu)
 {
-    const int depth = B.depth;
-    st.n_regions = static_cast<int>((B.n_paths + st.region - 1) / st.region);
-    const dim3 block(BLOCK);
-    const dim3 grid_paths(blocks_for(static_cast<int64_t>(st.n_regions) * st.region)); // one thread per slot
-    const dim3 grid_waves(blocks_for(static_cast<int64_t>(st.n_regions) * 64));        // one wave per region
-    if (tm)
-        tm->mark(s, RenderTimers::OTHER);
-    hipLaunchKernelGGL((k_raygen<R>), grid_paths, block, 0, s, cam, B, st);
-    for (int b = 0; b < depth; b++)
-    {
-        if (tm)
-            tm->mark(s, RenderTimers::EXTEND);
-        hipLaunchKernelGGL((k_extend<R, BRUTE>), grid_waves, block, 0, s, S, st, b);
-        if (tm)
-            tm->mark(s, RenderTimers::SHADE);
-        {
-            const bool tab = S.n_mats <= SHADE_LDS_MATS && S.n_lights <= SHADE_LDS_LIGHTS;
-            const bool nrm = S.n_tris <= SHADE_LDS_TRIS;
-            if (tab && nrm)
-                hipLaunchKernelGGL((k_shade<R, true, true>), grid_waves, block, 0, s, S, B, st, b);
-            else if (tab)
-                hipLaunchKernelGGL((k_shade<R, true, false>), grid_waves, block, 0, s, S, B, st, b);
-            else if (nrm)
-                hipLaunchKernelGGL((k_shade<R, false, true>), grid_waves, block, 0, s, S, B, st, b);
-            else
-                hipLaunchKernelGGL((k_shade<R, false, false>), grid_waves, block, 0, s, S, B, st, b);
-        }
-        if (S.n_square > 0)
-        {
-            if (tm)
-                tm->mark(s, RenderTimers::SHADOW);
-            hipLaunchKernelGGL((k_shadow<R, BRUTE>), grid_waves, block, 0, s, S, B, st, b);
-        }
-    }
-    if (tm)
-        tm->mark(s, RenderTimers::OTHER);
-    hipLaunchKernelGGL((k_resolve<R>), dim3(blocks_for(B.n_paths)), block, 0, s, S, B, st);
-    hipLaunchKernelGGL((k_accumulate<R>), dim3(blocks_for(B.n_pix)), block, 0, s, B, st, sum);
-    hipLaunchKernelGGL((k_reduce_stats<R>), dim3(1), block, 0, s, B, st);
-    if (tm)
-        tm->mark(s, RenderTimers::END);
-    HIP_CHECK(hipGetLastError());
+    int per_cu = blocks_per_cu;
+    if (per_cu <= 0)
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0));
+    per_cu = std::max(per_cu, 1);
+    int64_t blocks = static_cast<int64_t>(per_cu) * n_cus;
+    blocks = std::min<int64_t>(blocks, MAX_TRACE_WAVES / (BLOCK / 64));
+    blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (n_paths + BLOCK - 1) / BLOCK));
+    return static_cast<int>(blocks);
 }
 
 template <class R, bool BRUTE>
-static void run_batch_persistent(const DScene<R> &S, const DCamera &cam, const DBatch &B, DState<R> &st, double *sum, hipStream_t s,
-                                 RenderTimers *tm, int paths_per_wave)
+static void run_batch(const DScene<R> &S, const DCamera &cam, const DBatch &B, DState<R> &st, double *sum, hipStream_t s,
+                      RenderTimers *tm, int chunk, int n_cus, int blocks_per_cu)
 {
-    const int64_t n_waves = (B.n_paths + paths_per_wave - 1) / paths_per_wave;
-    st.n_regions = static_cast<int>(n_waves);
     const dim3 block(BLOCK);
-    const dim3 grid(blocks_for(n_waves * 64));
     if (tm)
-        tm->mark(s, RenderTimers::EXTEND);
-    const bool tab = S.n_mats <= SHADE_LDS_MATS && S.n_lights <= SHADE_LDS_LIGHTS;
-    const bool nrm = S.n_tris <= SHADE_LDS_TRIS;
+        tm->mark(s, RenderTimers::TRACE);
+    const bool tab = S.n_mats <= LDS_MATS && S.n_lights <= LDS_LIGHTS;
+    const bool nrm = S.n_tris <= LDS_TRIS;
+    auto go = [&](auto kernel) {
+        const int blocks = persistent_blocks(kernel, n_cus, B.n_paths, blocks_per_cu);
+        st.n_waves = blocks * (BLOCK / 64);
+        hipLaunchKernelGGL(kernel, dim3(blocks), block, 0, s, S, cam, B, st, chunk);
+    };
     if (tab && nrm)
-        hipLaunchKernelGGL((k_trace<R, BRUTE, true, true>), grid, block, 0, s, S, cam, B, st, paths_per_wave);
+        go(k_trace<R, BRUTE, true, true>);
     else if (tab)
-        hipLaunchKernelGGL((k_trace<R, BRUTE, true, false>), grid, block, 0, s, S, cam, B, st, paths_per_wave);
+        go(k_trace<R, BRUTE, true, false>);
     else if (nrm)
-        hipLaunchKernelGGL((k_trace<R, BRUTE, false, true>), grid, block, 0, s, S, cam, B, st, paths_per_wave);
+        go(k_trace<R, BRUTE, false, true>);
     else
-        hipLaunchKernelGGL((k_trace<R, BRUTE, false, false>), grid, block, 0, s, S, cam, B, st, paths_per_wave);
+        go(k_trace<R, BRUTE, false, false>);
+    if (tm)
+        tm->mark(s, RenderTimers::RESOLVE);
+    hipLaunchKernelGGL((k_resolve<R>), dim3(blocks_for(B.n_paths)), block, 0, s, S, B, st);
+    if (tm)
+        tm->mark(s, RenderTimers::ACCUMULATE);
+    hipLaunchKernelGGL((k_accumulate<R>), dim3(blocks_for(B.n_pix)), block, 0, s, B, st, sum);
     if (tm)
         tm->mark(s, RenderTimers::OTHER);
-    hipLaunchKernelGGL((k_resolve_records<R>), dim3(blocks_for(B.n_paths)), block, 0, s, S, B, st);
-    hipLaunchKernelGGL((k_accumulate<R>), dim3(blocks_for(B.n_pix)), block, 0, s, B, st, sum);
     hipLaunchKernelGGL((k_reduce_stats<R>), dim3(1), block, 0, s, B, st);
     if (tm)
         tm->mark(s, RenderTimers::END);
@@ -624,8 +557,8 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     const int depth = o.depth > 0 ? o.depth : sc.depth;
     const int spp = o.spp > 0 ? o.spp : sc.spp;
     const int spp_total = o.spp_total > 0 ? o.spp_total : spp;
-    if (depth > 4095)
-        throw std::runtime_error("arg: depth above 4095 is not supported");
+    if (depth > 65535)
+        throw std::runtime_error("arg: depth above 65535 is not supported");
 
     // rows / columns inside DrawRegion (inclusive ends), clipped to the image
     int r0 = std::max(sc.region[0], 0), r1 = std::min(sc.region[2], sc.height - 1) + 1;
@@ -660,11 +593,10 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     const int64_t cap = pix_per_chunk * samples_per_batch;
     if (cap >= (int64_t(1) << 31))
         throw std::runtime_error("arg: batch_paths must stay below 2^31");
-    const int deferred = sc.n_square_lights() > 0 ? static_cast<int>(sc.lights.size()) : 0;
-    int region = region_slots > 0 ? region_slots : 512;
-    region = std::max(64, (region + 63) / 64 * 64);
-    im.ensure_state(cap, depth, deferred, region);
+    const int chunk = std::max(64, chunk_paths);
+    im.ensure_state(cap, depth);
     HIP_CHECK(hipMemsetAsync(im.st.stats, 0, sizeof(unsigned long long) * 8, s));
+    HIP_CHECK(hipMemsetAsync(im.st.pool, 0, sizeof(unsigned int), s));
 
     auto S = make_dscene<R>(sc, *geo_, im.tri_pre.p, im.mats.p, im.lights.p, im.tri_nrm.p, brute_);
     DCamera cam = make_camera(sc);
@@ -691,18 +623,10 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
             B.seed = o.seed;
             B.n_pix = static_cast<int64_t>(nr) * n_cols;
             B.n_paths = B.n_pix * B.n_samples;
-            if (paths_per_wave > 0)
-            {
-                const int ppw = std::max(64, paths_per_wave);
-                if (brute_)
-                    run_batch_persistent<R, true>(S, cam, B, im.st, d_sum, s, tm, ppw);
-                else
-                    run_batch_persistent<R, false>(S, cam, B, im.st, d_sum, s, tm, ppw);
-            }
-            else if (brute_)
-                run_batch<R, true>(S, cam, B, im.st, d_sum, s, tm);
+            if (brute_)
+                run_batch<R, true>(S, cam, B, im.st, d_sum, s, tm, chunk, n_cus_, trace_blocks_per_cu);
             else
-                run_batch<R, false>(S, cam, B, im.st, d_sum, s, tm);
+                run_batch<R, false>(S, cam, B, im.st, d_sum, s, tm, chunk, n_cus_, trace_blocks_per_cu);
             passes++;
         }
     }
@@ -718,6 +642,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     stats.shadow_rays = h_stats[1];
     stats.paths = h_stats[2];
     stats.wave_iterations = h_stats[3];
+    stats.records = h_stats[4];
     stats.passes = passes;
     stats.ms_total = ms;
     if (tm)

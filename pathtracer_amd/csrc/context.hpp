@@ -1,4 +1,4 @@
-// One rendering context per GPU: device copies of the scene and the wavefront state.
+// One rendering context per GPU: device copies of the scene and the per-batch path state.
 #pragma once
 #include "bvh.hpp"
 #include "scene.hpp"
@@ -28,9 +28,9 @@ struct RenderOpts
 
 struct RenderStats
 {
-    uint64_t paths = 0, segments = 0, shadow_rays = 0, passes = 0, wave_iterations = 0;
+    uint64_t paths = 0, segments = 0, shadow_rays = 0, passes = 0, wave_iterations = 0, records = 0;
     double ms_total = 0;
-    double ms_class[4] = {0, 0, 0, 0}; // extend, shade, shadow, other
+    double ms_class[4] = {0, 0, 0, 0}; // trace, resolve, accumulate, other
 };
 
 // per-kernel-class timing with HIP events on the render stream (profiling mode only)
@@ -38,9 +38,9 @@ struct RenderTimers
 {
     enum
     {
-        EXTEND = 0,
-        SHADE = 1,
-        SHADOW = 2,
+        TRACE = 0,
+        RESOLVE = 1,
+        ACCUMULATE = 2,
         OTHER = 3,
         END = 4
     };
@@ -75,10 +75,10 @@ public:
     // scenes up to this many triangles are intersected by the all-triangles loop
     int brute_force_limit = 64;
     int64_t default_batch_paths = int64_t(1) << 23;
-    // slots per wave-private queue region (multiple of 64)
-    int region_slots = 512;
-    // > 0: persistent tracer, this many consecutive path ids per wave
-    int paths_per_wave = 1024;
+    // path ids a wave of the tracer takes from the pool at a time (>= 64)
+    int chunk_paths = 256;
+    // workgroups of the tracer per compute unit (<= 0: what the occupancy calculator reports)
+    int trace_blocks_per_cu = 0;
 
     struct Geometry;
     template <class R> struct Impl;
@@ -88,6 +88,7 @@ private:
     template <class R> void render_impl(Impl<R> &im, const RenderOpts &o, double *d_sum, RenderStats &stats);
 
     int device_;
+    int n_cus_ = 1;
     void *stream_ = nullptr;
     Scene scene_;
     Bvh bvh_;

@@ -1,26 +1,19 @@
-// Wavefront path-tracing kernels for gfx950 (wave64).  Templated on the scalar type R and on the
-// intersector (BRUTE: every triangle, in face order, from a wave-uniform table the compiler reads
-// through the scalar cache; otherwise the flattened BVH with a per-lane LDS stack).
+// Path-tracing kernels for gfx950 (wave64).  Templated on the scalar type R and on the intersector
+// (BRUTE: two-phase all-triangles test -- f32 plane records from a wave-uniform table the compiler
+// reads through the scalar cache, then the exact test on the survivors; otherwise the flattened
+// BVH with a per-lane LDS stack).
 //
 // Kernel <-> reference map (paths relative to the reference root):
-//   k_raygen / k_first_hit ... cPathTracer::GenerateRay        src/tracing/cPathTracer.cpp:129-213
-//   closest_hit .............. cAccelStruct::RayCast           src/geometry/cAccelStruct.cpp:28-54
-//   visible .................. cAccelStruct::VisTest           src/geometry/cAccelStruct.cpp:56-87
-//   k_extend ................. the RayCast call of the bounce loop, cPathTracer.cpp:596
-//   k_shade .................. bounce body: miss/emitter termination, shading normal, NEE set-up
-//                              (cBxDF::Sample_Li, src/tracing/cBxDF.cpp:16-52), next direction
-//                              (Sample_f), cPathTracer.cpp:598-673; packs the survivors to the
-//                              front of the wave's own queue region (wave64 ballot + popcount
-//                              prefix; no atomics, no barriers)
-//   k_shadow ................. the VisTest calls of Sample_Li and the in-order sum of the per-light
-//                              terms
-//   k_resolve / k_accumulate . back-to-front combine with the per-bounce max-clamp, and the
-//                              per-pixel average in sample order, cPathTracer.cpp:679-692
-//
-// Queue layout: the N path slots of a batch are cut into regions of `region` consecutive slots,
-// one region per WAVE.  A wave only ever reads and writes its own region (of the ray queue, the hit
-// records, the deferred-NEE list), so dead paths are squeezed out with a ballot/popcount prefix
-// inside the wave and the per-region live count replaces any global queue tail.
+//   primary_ray / k_camera_rays  cPathTracer::GenerateRay        src/tracing/cPathTracer.cpp:129-213
+//   closest_hit / k_raycast .... cAccelStruct::RayCast           src/geometry/cAccelStruct.cpp:28-54
+//   visible / k_vistest ........ cAccelStruct::VisTest           src/geometry/cAccelStruct.cpp:56-87
+//   k_trace .................... the bounce loop of one primary ray, cPathTracer.cpp:555-673:
+//                                RayCast, miss / emitter termination, shading normal, NEE over all
+//                                lights with their VisTest (cBxDF::Sample_Li, src/tracing/cBxDF.cpp:
+//                                16-52), next direction (Sample_f); one (direct, coefficient) record
+//                                per bounce
+//   k_resolve / k_accumulate ... back-to-front combine with the per-bounce max-clamp, and the
+//                                per-pixel average in sample order, cPathTracer.cpp:679-692
 #pragma once
 #include "bvh.hpp"
 #include "device_math.hpp"
@@ -30,11 +23,7 @@ namespace ptx
 
 constexpr int BLOCK = 256;      // threads per workgroup (4 waves)
 constexpr int BVH_STACK = 48;   // per-lane traversal stack entries (LDS)
-// hit word packing: 20 bits of intersector-order triangle index + 1, 12 bits of material id + 1
-constexpr uint32_t HIT_TRI_MASK = 0xFFFFFu;
-constexpr int HIT_MAT_SHIFT = 20;
-constexpr int MAX_TRIS = (1 << 20) - 2, MAX_MATS = (1 << 12) - 2;
-constexpr int MAX_LIGHTS = 32;  // lights per scene when NEE terms are deferred to k_shadow (mask bits)
+constexpr int MAX_MATS = 0xFFFE; // the path state word keeps the tail material in 16 bits
 
 template <class R> struct DScene
 {
@@ -85,32 +74,17 @@ __device__ __forceinline__ int local_row_to_image_row(const DBatch &b, int lr)
     return b.region_row0 + (bi * b.row_stride + b.row_phase) * b.band + off;
 }
 
-// per-batch device state, SoA.  Arrays indexed by `slot` are queue slots (region-wise dense,
-// re-packed every bounce); arrays indexed by `pid` are path slots (pid = sample_local * n_pix +
-// pixel_local = the slot the path started in).
+// per-batch device state.  pid = sample_local * n_pix + pixel_local numbers the paths of a batch.
 template <class R> struct DState
 {
-    R *ray_o[2][3], *ray_d[2][3]; // [2 queues][component][N]
-    uint32_t *q_pid[2];           // [N]
-    int32_t *q_prim[2];           // [N] intersector-order triangle the ray starts on (-1: camera)
-    uint32_t *hit_prim;           // [N] hit word: 0 = miss, else (triangle + 1) | (material + 1) << 20
-    R *hit_pt[3];                 // [N]
-    R *stack_d;                   // [depth][3][N] by pid
-    R *stack_c;                   // [depth][3][N] by pid
-    uint32_t *path_state;         // [N] by pid: (len << 16) | (tail material + 1)
-    R *stack;                     // [N][depth][6] by pid: direct rgb, coefficient rgb (persistent tracer)
-    // deferred NEE (only when the scene has square lights).  The per-light terms stay at the
-    // queue slot of the path; only the list of slots that need visibility tests is packed.
-    uint32_t *nee_idx;            // [N] region-wise dense list of slots with pending tests
-    uint32_t *nee_mask;           // [N] by slot: bit l = light l needs a visibility test
-    R *nee_c;                     // [n_lights][3][N] by slot: per-light contribution
-    uint32_t *cnt[2];             // [n_regions] live rays of each region, per queue buffer
-    uint32_t *nee_cnt;            // [n_regions] pending-NEE paths of each region
-    unsigned long long *wave_stats; // [n_regions][4] segments, shadow tests, wave iterations, spare
-    unsigned long long *stats;    // [8] totals (filled by k_reduce_stats)
-    int64_t N;                    // capacity (paths per batch)
-    int region;                   // slots per wave region (multiple of 64)
-    int n_regions;                // regions in use by the current batch
+    R *stack;                       // [N][depth][6] by pid: direct rgb, coefficient rgb of every bounce
+    uint32_t *path_state;           // [N] by pid: (len << 16) | (tail material + 1)
+    R *result;                      // [3][N] by pid: resolved per-sample radiance
+    unsigned long long *wave_stats; // [n_waves][4] segments, shadow tests, wave iterations, records
+    unsigned long long *stats;      // [8] totals (filled by k_reduce_stats)
+    unsigned int *pool;             // next unassigned path id of the current batch
+    int64_t N;                      // capacity (paths per batch)
+    int n_waves;                    // waves of the current batch
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -194,23 +168,35 @@ __device__ __forceinline__ unsigned long long prefilter_mask(const float *__rest
     const float dx = float(d.x), dy = float(d.y), dz = float(d.z);
     const float To = 1.75f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
     uint32_t mlo = 0, mhi = 0;
+    // The records never change while a kernel runs.  Reading them through the constant address
+    // space tells the compiler so: the wave-uniform loads stay scalar-cache loads even though the
+    // tracer has an atomic (its path-id pool) that it must assume may write anywhere.
+    typedef const float __attribute__((address_space(4))) const_float;
+    const_float *PQc = (const_float *)(uintptr_t)PQ;
     for (int r = 0; r < n_recs; r++)
     {
-        const float *__restrict__ P = PQ + r * PQ_STRIDE;
-        const float nd = P[0] * dx + P[1] * dy + P[2] * dz;
-        const float no = P[3] - (P[0] * ox + P[1] * oy + P[2] * oz);
+        const_float *P = PQc + r * PQ_STRIDE;
+        // every field is read up front (one burst of scalar loads) and the tests are combined
+        // without short-circuit evaluation: no branches and no load is waited for inside them
+        const float nx = P[0], ny = P[1], nz = P[2], pc = P[3];
+        const float ax = P[4], ay = P[5], az = P[6], a0 = P[7];
+        const float bx = P[8], by = P[9], bz = P[10], b0 = P[11];
+        const float uc = P[12], uh = P[13], vc = P[14], vh = P[15];
+        const float Eu = P[16], Eu0 = P[17], Ev = P[18], Ev0 = P[19], Et = P[20], Sc = P[21], bthr = P[22];
+        const float nd = nx * dx + ny * dy + nz * dz;
+        const float no = pc - (nx * ox + ny * oy + nz * oz);
         const float rr = __builtin_amdgcn_rcpf(nd);
         const float t = no * rr;
-        const float W = (To + P[21]) * (rr * rr);
+        const float W = (To + Sc) * (rr * rr);
         const float X = fmaf(t, dx, ox), Y = fmaf(t, dy, oy), Z = fmaf(t, dz, oz);
-        const float u = fmaf(P[4], X, fmaf(P[5], Y, fmaf(P[6], Z, -P[7])));
-        const float v = fmaf(P[8], X, fmaf(P[9], Y, fmaf(P[10], Z, -P[11])));
-        const float eu = fmaf(P[16], W, P[17]), ev = fmaf(P[18], W, P[19]), et = P[20] * W;
+        const float u = fmaf(ax, X, fmaf(ay, Y, fmaf(az, Z, -a0)));
+        const float v = fmaf(bx, X, fmaf(by, Y, fmaf(bz, Z, -b0)));
+        const float eu = fmaf(Eu, W, Eu0), ev = fmaf(Ev, W, Ev0), et = Et * W;
         // all comparisons are false on NaN / infinity soup, which keeps the candidate
-        const bool out = (fabsf(u - P[12]) > P[13] + eu) || (fabsf(v - P[14]) > P[15] + ev) || (t + et < tmin) || (t - et > tmax);
+        const bool out = (fabsf(u - uc) > uh + eu) | (fabsf(v - vc) > vh + ev) | (t + et < tmin) | (t - et > tmax);
         const float s = (u + v) - 1.0f, es = eu + ev;
-        const bool ka = !(out || s > es);
-        const bool kb = !(out || s + es < P[22]);
+        const bool ka = !(out | (s > es));
+        const bool kb = !(out | (s + es < bthr));
         const uint32_t bits = (ka ? 1u : 0u) | (kb ? 2u : 0u);
         if (r < 16)
             mlo |= bits << (2 * r);
@@ -493,353 +479,31 @@ __global__ void __launch_bounds__(BLOCK)
     vis[i] = visible<R, BRUTE>(S, a, b, stk) ? 1 : 0;
 }
 
-// ---------------------------------------------------------------------------------------------
-// wavefront kernels.  One wave per queue region; every loop below has a wave-uniform trip count.
-// ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int global_wave() { return int((blockIdx.x * BLOCK + threadIdx.x) >> 6); }
 __device__ __forceinline__ int lane_id() { return int(threadIdx.x & 63); }
 
-template <class R> __global__ void __launch_bounds__(BLOCK) k_raygen(DCamera cam, DBatch B, DState<R> st)
-{
-    int64_t pid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (pid < (int64_t)st.n_regions * st.region && (pid % st.region) == 0)
-    {
-        const int64_t left = B.n_paths - pid;
-        const int g = int(pid / st.region);
-        st.cnt[0][g] = uint32_t(left < 0 ? 0 : (left < st.region ? left : st.region));
-        st.wave_stats[g * 4 + 0] = 0, st.wave_stats[g * 4 + 1] = 0, st.wave_stats[g * 4 + 2] = 0, st.wave_stats[g * 4 + 3] = 0;
-    }
-    if (pid >= B.n_paths)
-        return;
-    int64_t pix = pid % B.n_pix;
-    int lr = B.row0 + int(pix / B.n_cols), col = B.col0 + int(pix % B.n_cols);
-    int row = local_row_to_image_row(B, lr);
-    V3<R> o, d;
-    primary_ray<R>(cam, col, row, o, d);
-    st.ray_o[0][0][pid] = o.x, st.ray_o[0][1][pid] = o.y, st.ray_o[0][2][pid] = o.z;
-    st.ray_d[0][0][pid] = d.x, st.ray_d[0][1][pid] = d.y, st.ray_d[0][2][pid] = d.z;
-    st.q_pid[0][pid] = uint32_t(pid);
-    st.q_prim[0][pid] = -1;
-    st.path_state[pid] = uint32_t(B.depth) << 16; // default: survives every bounce, zero tail
-}
-
-template <class R, bool BRUTE> __global__ void __launch_bounds__(BLOCK) k_extend(DScene<R> S, DState<R> st, int bounce)
-{
-    __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : BVH_STACK * BLOCK];
-    int *stk = intersector_scratch<R, BRUTE>(S, lds_raw); // all threads: contains a barrier
-    const int q = bounce & 1, g = global_wave(), lane = lane_id();
-    if (g >= st.n_regions)
-        return;
-    const int n = int(st.cnt[q][g]);
-    const int64_t base = (int64_t)g * st.region;
-    for (int j0 = 0; j0 < n; j0 += 64)
-    {
-        const int j = j0 + lane;
-        if (j < n)
-        {
-            const int64_t i = base + j;
-            V3<R> o = {st.ray_o[q][0][i], st.ray_o[q][1][i], st.ray_o[q][2][i]};
-            V3<R> d = {st.ray_d[q][0][i], st.ray_d[q][1][i], st.ray_d[q][2][i]};
-            V3<R> p = {R(0), R(0), R(0)};
-            int k = closest_hit<R, BRUTE>(S, o, d, p, stk, st.q_prim[q][i]);
-            st.hit_prim[i] = k < 0 ? 0u : (uint32_t(k + 1) | (uint32_t(S.tri_mat[k] + 1) << HIT_MAT_SHIFT));
-            st.hit_pt[0][i] = p.x, st.hit_pt[1][i] = p.y, st.hit_pt[2][i] = p.z;
-        }
-    }
-    if (lane == 0 && n > 0)
-    {
-        st.wave_stats[g * 4 + 0] += (unsigned long long)n;
-        st.wave_stats[g * 4 + 2] += (unsigned long long)((n + 63) >> 6);
-    }
-}
-
-// RNG key of a path: which image pixel and global sample index the path slot `pid` belongs to
-__device__ __forceinline__ uint64_t path_rng_key(const DBatch &B, uint32_t pid, uint32_t &sample)
-{
-    const int64_t pix = int64_t(pid) % B.n_pix;
-    const int s_local = int(int64_t(pid) / B.n_pix);
-    const int lr = B.row0 + int(pix / B.n_cols), col = B.col0 + int(pix % B.n_cols);
-    const uint32_t pixel = uint32_t(local_row_to_image_row(B, lr)) * uint32_t(B.image_width) + uint32_t(col);
-    sample = uint32_t(B.sample0 + s_local);
-    return rng_pixel_key(B.seed, pixel);
-}
-
-// On gfx9-class ISAs vector loads and stores retire in order on ONE counter, so a load issued
-// after a store waits for that store to be acknowledged.  k_shade therefore issues all its global
-// loads at the top of an iteration (the queue slot, prefetched one iteration ahead) and reads the
-// small tables -- materials, lights, per-triangle normals -- from LDS copies (LDS has its own
-// counter).  TAB: materials and lights fit LDS; NRM: the per-triangle normal table fits too.
-constexpr int SHADE_LDS_MATS = 48, SHADE_LDS_LIGHTS = 32, SHADE_LDS_TRIS = 64;
-
-template <class R, bool TAB, bool NRM>
-__global__ void __launch_bounds__(BLOCK) k_shade(DScene<R> S, DBatch B, DState<R> st, int bounce)
-{
-    __shared__ R lds_mats[TAB ? SHADE_LDS_MATS * MAT_STRIDE : 1];
-    __shared__ R lds_lights[TAB ? SHADE_LDS_LIGHTS * LIGHT_STRIDE : 1];
-    __shared__ R lds_nrm[NRM ? SHADE_LDS_TRIS * 4 : 1];
-    if (TAB)
-    {
-        for (int k = threadIdx.x; k < S.n_mats * MAT_STRIDE; k += BLOCK)
-            lds_mats[k] = S.mats[k];
-        for (int k = threadIdx.x; k < S.n_lights * LIGHT_STRIDE; k += BLOCK)
-            lds_lights[k] = S.lights[k];
-    }
-    if (NRM)
-        for (int k = threadIdx.x; k < S.n_tris * 4; k += BLOCK)
-            lds_nrm[k] = S.tri_nrm[k];
-    if (TAB || NRM)
-        __syncthreads();
-    const int q = bounce & 1, qn = q ^ 1, g = global_wave(), lane = lane_id();
-    if (g >= st.n_regions)
-        return;
-    const int n = int(st.cnt[q][g]);
-    const int64_t base = (int64_t)g * st.region;
-    const int64_t N = st.N;
-    int n_out = 0, n_nee = 0; // wave-uniform running counts of this region's two output lists
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const bool last_bounce = bounce + 1 >= B.depth;
-
-    // first-level loads of one queue slot; issued one iteration ahead of their use so that the
-    // memory latency of iteration k+1 overlaps the arithmetic of iteration k
-    struct Item
-    {
-        uint32_t pid, hit;
-        V3<R> p, d;
-    };
-    auto load_item = [&](int jj) {
-        Item it;
-        it.pid = 0, it.hit = 0;
-        it.p = {R(0), R(0), R(0)}, it.d = {R(0), R(0), R(0)};
-        if (jj < n)
-        {
-            const int64_t ii = base + jj;
-            it.pid = st.q_pid[q][ii];
-            it.hit = st.hit_prim[ii];
-            it.p = {st.hit_pt[0][ii], st.hit_pt[1][ii], st.hit_pt[2][ii]};
-            it.d = {st.ray_d[q][0][ii], st.ray_d[q][1][ii], st.ray_d[q][2][ii]};
-        }
-        return it;
-    };
-    Item next = load_item(lane);
-
-    for (int j0 = 0; j0 < n; j0 += 64)
-    {
-        const int j = j0 + lane;
-        const int64_t i = base + j;
-        const Item cur = next;
-        next = load_item(j + 64);
-        // ---- termination rules (miss / no material -> tail 0; emitter -> tail Ka) ----------------
-        bool shaded = false;
-        const uint32_t pid = cur.pid;
-        const int hit_k = int(cur.hit & HIT_TRI_MASK) - 1;
-        const int mat_id = int(cur.hit >> HIT_MAT_SHIFT) - 1;
-        const int mrow = (mat_id < 0 ? 0 : mat_id) * MAT_STRIDE;
-        const R *m; // the address space (LDS or global) is fixed at compile time
-        if constexpr (TAB)
-            m = lds_mats + mrow;
-        else
-            m = S.mats + mrow;
-        if (j < n)
-        {
-            if (mat_id < 0)
-                st.path_state[pid] = uint32_t(bounce) << 16;
-            else if (m[13] != R(0))
-                st.path_state[pid] = (uint32_t(bounce) << 16) | uint32_t(mat_id + 1);
-            else
-                shaded = true;
-        }
-        const bool alive = shaded && S.enable_indirect && !last_bounce;
-        const unsigned long long am = __ballot(alive);
-        bool defer = false;
-        uint32_t mask = 0;
-
-        if (shaded)
-        {
-            const V3<R> p = cur.p;
-            const V3<R> wo = -cur.d;
-            // shading normal: precomputed per triangle when it is flat (its three vertex normals
-            // are equal) or when barycentric normals are off; else interpolated
-            R fn0, fn1, fn2, fn3;
-            if (NRM)
-                fn0 = lds_nrm[hit_k * 4], fn1 = lds_nrm[hit_k * 4 + 1], fn2 = lds_nrm[hit_k * 4 + 2], fn3 = lds_nrm[hit_k * 4 + 3];
-            else
-            {
-                const R *__restrict__ fn = S.tri_nrm + (size_t)hit_k * 4;
-                fn0 = fn[0], fn1 = fn[1], fn2 = fn[2], fn3 = fn[3];
-            }
-            V3<R> nrm = {fn0, fn1, fn2};
-            if (fn3 == R(0))
-            {
-                const int face = S.tri_face[hit_k];
-                const float *__restrict__ vp = S.verts + (size_t)face * 9;
-                const float *__restrict__ np = S.normals + (size_t)face * 9;
-                V3<R> a = {R(vp[0]), R(vp[1]), R(vp[2])}, b = {R(vp[3]), R(vp[4]), R(vp[5])}, c = {R(vp[6]), R(vp[7]), R(vp[8])};
-                V3<R> w = barycentric(p, a, b, c);
-                V3<R> acc = w.x * V3<R>{R(np[0]), R(np[1]), R(np[2])};
-                acc = acc + w.y * V3<R>{R(np[3]), R(np[4]), R(np[5])};
-                acc = acc + w.z * V3<R>{R(np[6]), R(np[7]), R(np[8])};
-                nrm = fast_normalized(acc);
-            }
-            uint32_t sample;
-            const uint64_t key = path_rng_key(B, pid, sample);
-
-            // ---- next direction first: the survivor leaves for its new slot right away ---------
-            V3<R> coef = {R(0), R(0), R(0)};
-            if (S.enable_indirect)
-            {
-                const R x1 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 0);
-                const R x2 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 1);
-                V3<R> wi;
-                bxdf_sample(m, nrm, wo, x1, x2, wi, coef);
-                if (alive)
-                {
-                    const int64_t slot = base + n_out + __popcll(am & lt_mask);
-                    st.ray_o[qn][0][slot] = p.x, st.ray_o[qn][1][slot] = p.y, st.ray_o[qn][2][slot] = p.z;
-                    st.ray_d[qn][0][slot] = wi.x, st.ray_d[qn][1][slot] = wi.y, st.ray_d[qn][2][slot] = wi.z;
-                    st.q_pid[qn][slot] = pid;
-                    st.q_prim[qn][slot] = hit_k;
-                }
-            }
-            else
-                st.path_state[pid] = uint32_t(bounce + 1) << 16;
-            R *C = st.stack_c + (size_t)bounce * 3 * N;
-            C[pid] = coef.x, C[N + pid] = coef.y, C[2 * N + pid] = coef.z;
-
-            // ---- NEE over all lights, in order ---------------------------------------------------
-            V3<R> direct = {R(0), R(0), R(0)};
-            for (int l = 0; l < S.n_lights; l++)
-            {
-                const R *L;
-                if constexpr (TAB)
-                    L = lds_lights + l * LIGHT_STRIDE;
-                else
-                    L = S.lights + (size_t)l * LIGHT_STRIDE;
-                V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
-                R pdf;
-                const R x1 = rng_draw<R>(key, sample, bounce, 4 * l + 0);
-                const R x2 = rng_draw<R>(key, sample, bounce, 4 * l + 1);
-                const bool square = L[0] == R(0);
-                if (square)
-                    pdf = square_light_sample(L, p, x1, x2, ro, rd);
-                else
-                    pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bounce, 4 * l + 2), ro, rd);
-                V3<R> term = {R(0), R(0), R(0)};
-                bool valid = false;
-                if (!(pdf < R(1e-10)))
-                {
-                    R cn = dot(nrm, -rd);
-                    if (!(cn < R(0)))
-                    {
-                        V3<R> f = bxdf_eval(m, rd, wo, nrm);
-                        const R w = cn / pdf;
-                        term = {(L[1] * w) * f.x, (L[2] * w) * f.y, (L[3] * w) * f.z};
-                        valid = true;
-                    }
-                }
-                if (S.n_square > 0)
-                {
-                    R *cdst = st.nee_c + (size_t)l * 3 * N;
-                    cdst[i] = term.x, cdst[N + i] = term.y, cdst[2 * N + i] = term.z;
-                }
-                if (valid && square)
-                    mask |= 1u << l;
-                direct = direct + term;
-            }
-            defer = mask != 0;
-            if (!defer)
-            {
-                R *D = st.stack_d + (size_t)bounce * 3 * N;
-                D[pid] = direct.x, D[N + pid] = direct.y, D[2 * N + pid] = direct.z;
-            }
-        }
-        n_out += __popcll(am);
-        // paths with NEE terms that need a visibility test -> this region's shadow list
-        if (S.n_square > 0)
-        {
-            const unsigned long long dm = __ballot(defer);
-            if (defer)
-            {
-                st.nee_idx[base + n_nee + __popcll(dm & lt_mask)] = uint32_t(j);
-                st.nee_mask[i] = mask;
-            }
-            n_nee += __popcll(dm);
-        }
-    }
-    if (lane == 0)
-    {
-        st.cnt[qn][g] = uint32_t(n_out);
-        st.nee_cnt[g] = uint32_t(n_nee);
-    }
-}
-
-template <class R, bool BRUTE> __global__ void __launch_bounds__(BLOCK) k_shadow(DScene<R> S, DBatch B, DState<R> st, int bounce)
-{
-    __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : BVH_STACK * BLOCK];
-    int *stk = intersector_scratch<R, BRUTE>(S, lds_raw); // all threads: contains a barrier
-    const int q = bounce & 1, g = global_wave(), lane = lane_id();
-    if (g >= st.n_regions)
-        return;
-    const int n = int(st.nee_cnt[g]);
-    const int64_t base = (int64_t)g * st.region;
-    const int64_t N = st.N;
-    const int nl = S.n_lights;
-    unsigned long long tests = 0;
-    for (int j0 = 0; j0 < n; j0 += 64)
-    {
-        const int j = j0 + lane;
-        if (j < n)
-        {
-            const int64_t i = base + st.nee_idx[base + j];
-            const uint32_t pid = st.q_pid[q][i], mask = st.nee_mask[i];
-            const V3<R> p2 = {st.hit_pt[0][i], st.hit_pt[1][i], st.hit_pt[2][i]};
-            const int own = int(st.hit_prim[i] & HIT_TRI_MASK) - 1;
-            uint32_t sample;
-            const uint64_t key = path_rng_key(B, pid, sample);
-            V3<R> direct = {R(0), R(0), R(0)};
-            for (int l = 0; l < nl; l++)
-            {
-                const R *csrc = st.nee_c + (size_t)l * 3 * N;
-                V3<R> term = {csrc[i], csrc[N + i], csrc[2 * N + i]};
-                if (mask & (1u << l))
-                {
-                    // the light sample point is a pure function of the path's random numbers:
-                    // regenerated here instead of being carried through memory
-                    const R *__restrict__ L = S.lights + (size_t)l * LIGHT_STRIDE;
-                    const R x1 = rng_draw<R>(key, sample, bounce, 4 * l + 0);
-                    const R x2 = rng_draw<R>(key, sample, bounce, 4 * l + 1);
-                    const V3<R> p1 = square_light_point(L, x1, x2);
-                    tests++;
-                    if (!visible<R, BRUTE>(S, p1, p2, stk, own))
-                        continue;
-                }
-                direct = direct + term;
-            }
-            R *D = st.stack_d + (size_t)bounce * 3 * N;
-            D[pid] = direct.x, D[N + pid] = direct.y, D[2 * N + pid] = direct.z;
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1)
-        tests += __shfl_down(tests, off, 64);
-    if (lane == 0 && tests)
-        st.wave_stats[g * 4 + 1] += tests; // the wave owns its row: plain read-modify-write
-}
+// Small tables -- materials, lights, per-triangle normals and material ids -- are read from LDS
+// copies when they fit.  TAB: materials and lights fit; NRM: the per-triangle tables fit too.
+constexpr int LDS_MATS = 48, LDS_LIGHTS = 32, LDS_TRIS = 64;
 
 // ---------------------------------------------------------------------------------------------
 // persistent tracer: every LANE carries one path in registers from its camera ray to its end --
 // closest hit, termination rules, shading normal, next direction, NEE with its visibility tests --
 // and then starts the next path of its wave's range (path regeneration).  No ray ever goes through
 // memory: the only global traffic is one 6-scalar stack record per shaded segment and one state
-// word per path.  Wave g owns the path ids [g * paths_per_wave, (g + 1) * paths_per_wave); every
-// wave leaves the loop once its range is used up and its 64 lanes are idle.
+// word per path.  Path ids come from one pool counter per batch: a wave whose idle lanes find its
+// range empty takes the next `chunk` ids with a single atomic add, so the grid is just large
+// enough to fill the GPU and all waves run dry together.  Every wave leaves the loop once the pool
+// is used up and its 64 lanes are idle.
 // ---------------------------------------------------------------------------------------------
 template <class R, bool BRUTE, bool TAB, bool NRM>
-__global__ void __launch_bounds__(BLOCK) k_trace(DScene<R> S, DCamera cam, DBatch B, DState<R> st, int paths_per_wave)
+__global__ void __launch_bounds__(BLOCK) k_trace(DScene<R> S, DCamera cam, DBatch B, DState<R> st, int chunk)
 {
     __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : BVH_STACK * BLOCK];
-    __shared__ R lds_mats[TAB ? SHADE_LDS_MATS * MAT_STRIDE : 1];
-    __shared__ R lds_lights[TAB ? SHADE_LDS_LIGHTS * LIGHT_STRIDE : 1];
-    __shared__ R lds_nrm[NRM ? SHADE_LDS_TRIS * 4 : 1];
-    __shared__ int lds_tmat[NRM ? SHADE_LDS_TRIS : 1];
+    __shared__ R lds_mats[TAB ? LDS_MATS * MAT_STRIDE : 1];
+    __shared__ R lds_lights[TAB ? LDS_LIGHTS * LIGHT_STRIDE : 1];
+    __shared__ R lds_nrm[NRM ? LDS_TRIS * 4 : 1];
+    __shared__ int lds_tmat[NRM ? LDS_TRIS : 1];
     if (TAB)
     {
         for (int k = threadIdx.x; k < S.n_mats * MAT_STRIDE; k += BLOCK)
@@ -857,13 +521,12 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene<R> S, DCamera cam, DBatc
     int *stk = intersector_scratch<R, BRUTE>(S, lds_raw);
     __syncthreads(); // the only barrier: from here on the waves of the workgroup are independent
     const int g = global_wave(), lane = lane_id();
-    if (g >= st.n_regions)
+    if (g >= st.n_waves)
         return;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t n_paths = uint32_t(B.n_paths);
-    const int64_t first = (int64_t)g * paths_per_wave;
-    uint32_t next = uint32_t(first < (int64_t)n_paths ? first : (int64_t)n_paths);
-    const uint32_t end = uint32_t(first + paths_per_wave < (int64_t)n_paths ? first + paths_per_wave : (int64_t)n_paths);
+    uint32_t next = 0, end = 0; // the wave's current range of path ids
+    bool drained = false;       // the pool has no ids left (wave-uniform)
     const uint32_t n_pix = uint32_t(B.n_pix), n_cols = uint32_t(B.n_cols);
     const int depth = B.depth;
 
@@ -872,12 +535,23 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene<R> S, DCamera cam, DBatc
     uint32_t pid = 0, sample = 0;
     int bounce = 0, prim = -1;
     uint64_t key = 0;
-    uint32_t n_seg = 0, n_tests = 0, n_iter = 0;
+    uint32_t n_seg = 0, n_tests = 0, n_iter = 0, n_rec = 0;
 
     for (;;)
     {
         // ---- idle lanes take the next path ids of the wave's range ------------------------------
         const unsigned long long idle = __ballot(!alive);
+        if (idle != 0ull && next == end && !drained)
+        {
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(st.pool, uint32_t(chunk));
+            base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+            if (base >= n_paths)
+                drained = true;
+            else
+                next = base, end = n_paths - base < uint32_t(chunk) ? n_paths : base + uint32_t(chunk);
+        }
         if (!alive)
         {
             const uint32_t cand = next + uint32_t(__popcll(idle & lt_mask));
@@ -899,7 +573,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene<R> S, DCamera cam, DBatc
             next = end - next < taken ? end : next + taken;
         }
         if (__ballot(alive) == 0ull)
-            break; // range used up and every lane idle
+            break; // pool used up and every lane idle
         n_iter++;
         if (!alive)
             continue;
@@ -1002,6 +676,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene<R> S, DCamera cam, DBatc
         R *rec = st.stack + ((size_t)pid * depth + bounce) * 6;
         rec[0] = direct.x, rec[1] = direct.y, rec[2] = direct.z;
         rec[3] = coef.x, rec[4] = coef.y, rec[5] = coef.z;
+        n_rec++;
         if (S.enable_indirect && bounce + 1 < depth)
         {
             o = p, d = wi, prim = hit_k;
@@ -1016,19 +691,20 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene<R> S, DCamera cam, DBatc
     {
         n_seg += __shfl_down(n_seg, off, 64);
         n_tests += __shfl_down(n_tests, off, 64);
+        n_rec += __shfl_down(n_rec, off, 64);
     }
     if (lane == 0)
     {
         st.wave_stats[g * 4 + 0] = n_seg;
         st.wave_stats[g * 4 + 1] = n_tests;
         st.wave_stats[g * 4 + 2] = n_iter;
-        st.wave_stats[g * 4 + 3] = 0;
+        st.wave_stats[g * 4 + 3] = n_rec;
     }
 }
 
 // one thread per path: folds the path's stack records back to front with the per-bounce max-clamp;
-// the per-sample result goes to stack_d[0][.][pid]
-template <class R> __global__ void __launch_bounds__(BLOCK) k_resolve_records(DScene<R> S, DBatch B, DState<R> st)
+// the per-sample result goes to result[.][pid]
+template <class R> __global__ void __launch_bounds__(BLOCK) k_resolve(DScene<R> S, DBatch B, DState<R> st)
 {
     const int64_t pid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (pid >= B.n_paths)
@@ -1059,49 +735,7 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_resolve_records(DS
         if (mx > R(1))
             fr /= mx, fg /= mx, fb /= mx;
     }
-    st.stack_d[pid] = fr, st.stack_d[N + pid] = fg, st.stack_d[2 * N + pid] = fb;
-}
-
-// one thread per path: folds its (direct, coefficient) stack back to front with the per-bounce
-// max-clamp; the per-sample result overwrites stack_d[0][.][pid]
-template <class R> __global__ void __launch_bounds__(BLOCK) k_resolve(DScene<R> S, DBatch B, DState<R> st)
-{
-    const int64_t pid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (pid >= B.n_paths)
-        return;
-    const int64_t N = st.N;
-    const uint32_t ps = st.path_state[pid];
-    const int len = int(ps >> 16), tm = int(ps & 0xffff);
-    R fr = R(0), fg = R(0), fb = R(0);
-    if (tm)
-    {
-        const R *m = S.mats + (size_t)(tm - 1) * MAT_STRIDE;
-        fr = m[0], fg = m[1], fb = m[2];
-    }
-    // the loop runs over the longest stack of the wave so that, at every step, all lanes read the
-    // SAME stack level at consecutive path ids (each 64-byte sector of a level is fetched once)
-    int wlen = len;
-    for (int off = 32; off > 0; off >>= 1)
-        wlen = max(wlen, __shfl_xor(wlen, off, 64));
-    for (int i = wlen - 1; i >= 0; i--)
-    {
-        if (i >= len)
-            continue;
-        const R *D = st.stack_d + (size_t)i * 3 * N, *C = st.stack_c + (size_t)i * 3 * N;
-        fr = D[pid] + C[pid] * fr;
-        fg = D[N + pid] + C[N + pid] * fg;
-        fb = D[2 * N + pid] + C[2 * N + pid] * fb;
-        R mx = fr;
-        if (fg > mx)
-            mx = fg;
-        if (fb > mx)
-            mx = fb;
-        if (R(0) > mx)
-            mx = R(0);
-        if (mx > R(1))
-            fr /= mx, fg /= mx, fb /= mx;
-    }
-    st.stack_d[pid] = fr, st.stack_d[N + pid] = fg, st.stack_d[2 * N + pid] = fb;
+    st.result[pid] = fr, st.result[N + pid] = fg, st.result[2 * N + pid] = fb;
 }
 
 // one thread per pixel of the batch: continues the running per-pixel sum in sample order
@@ -1118,19 +752,19 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_accumulate(DBatch 
     for (int s = 0; s < B.n_samples; s++)
     {
         const int64_t pid = (int64_t)s * B.n_pix + pix;
-        cr += double(st.stack_d[pid]) / B.spp_total;
-        cg += double(st.stack_d[N + pid]) / B.spp_total;
-        cb += double(st.stack_d[2 * N + pid]) / B.spp_total;
+        cr += double(st.result[pid]) / B.spp_total;
+        cg += double(st.result[N + pid]) / B.spp_total;
+        cb += double(st.result[2 * N + pid]) / B.spp_total;
     }
     dst[0] = cr, dst[1] = cg, dst[2] = cb;
 }
 
-// sums the per-region statistics of a batch into the totals (single workgroup, no atomics)
+// sums the per-wave statistics of a batch into the totals (single workgroup, no atomics)
 template <class R> __global__ void __launch_bounds__(BLOCK) k_reduce_stats(DBatch B, DState<R> st)
 {
     __shared__ unsigned long long part[4][BLOCK];
     unsigned long long a[4] = {0, 0, 0, 0};
-    for (int g = threadIdx.x; g < st.n_regions; g += BLOCK)
+    for (int g = threadIdx.x; g < st.n_waves; g += BLOCK)
         for (int c = 0; c < 4; c++)
             a[c] += st.wave_stats[g * 4 + c];
     for (int c = 0; c < 4; c++)
@@ -1148,7 +782,9 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_reduce_stats(DBatc
         st.stats[0] += part[0][0]; // segments
         st.stats[1] += part[1][0]; // shadow tests
         st.stats[2] += (unsigned long long)B.n_paths;
-        st.stats[3] += part[2][0]; // wave iterations of k_extend (64 lanes each)
+        st.stats[3] += part[2][0]; // wave iterations of k_trace (64 lanes each)
+        st.stats[4] += part[3][0]; // stack records written (shaded segments)
+        *st.pool = 0u;             // the next batch starts from path id 0
     }
 }
 

@@ -13,12 +13,12 @@ ppws = [int(x) for x in (sys.argv[5].split(",") if len(sys.argv) > 5 else ["0"])
 scene = pt.Scene.load_conf(os.path.join(ROOT, "config/cbox.conf"), root_dir=ROOT, width=1024, height=1024, spp=spp)
 out = torch.zeros((1024, 1024, 3), dtype=torch.float64, device="cuda")
 for lb, reg, ppw in itertools.product(batches, regions, ppws):
-    ctx = pt.Context(0, batch_paths=1 << lb, region_slots=reg, paths_per_wave=ppw)
+    ctx = pt.Context(0, batch_paths=1 << lb, chunk_paths=ppw, trace_blocks_per_cu=int(os.environ.get('PTX_BPC', '0')))
     ctx.build_accel(scene)
     ctx.render_device(out.data_ptr(), mode=mode, spp=8)
     st = ctx.render_device(out.data_ptr(), mode=mode, spp=spp)
     sp = ctx.render_device(out.data_ptr(), mode=mode, spp=spp, profile=True)
     util = st["segments"] / (64.0 * max(st["wave_iterations"], 1))
-    print("batch 2^%d region %4d ppw %5d: %8.1f Mpaths/s  ms %.1f | profiled: extend %.1f shade %.1f shadow %.1f other %.1f | lane util %.3f" % (
-        lb, reg, ppw, st["paths"] / st["ms_total"] / 1e3, st["ms_total"], sp["ms_extend"], sp["ms_shade"], sp["ms_shadow"], sp["ms_other"], util), flush=True)
+    print("batch 2^%d region %4d chunk %5d: %8.1f Mpaths/s  ms %.1f | profiled: trace %.1f resolve %.1f accumulate %.1f other %.1f | lane util %.3f" % (
+        lb, reg, ppw, st["paths"] / st["ms_total"] / 1e3, st["ms_total"], sp["ms_trace"], sp["ms_resolve"], sp["ms_accumulate"], sp["ms_other"], util), flush=True)
     del ctx
