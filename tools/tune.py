@@ -14,6 +14,9 @@ scene = pt.Scene.load_conf(os.path.join(ROOT, "config/cbox.conf"), root_dir=ROOT
 out = torch.zeros((1024, 1024, 3), dtype=torch.float64, device="cuda")
 for lb, reg, ppw in itertools.product(batches, regions, ppws):
     ctx = pt.Context(0, batch_paths=1 << lb, chunk_paths=ppw, trace_blocks_per_cu=int(os.environ.get('PTX_BPC', '0')))
+    for kv in filter(None, os.environ.get('PTX_OPTS', '').split(',')):
+        k, v = kv.split('=')
+        pt.api.check(pt._lib.lib().ptx_context_set_option(ctx._h, k.encode(), int(v)))
     ctx.build_accel(scene)
     ctx.render_device(out.data_ptr(), mode=mode, spp=8)
     st = ctx.render_device(out.data_ptr(), mode=mode, spp=spp)
