@@ -512,14 +512,12 @@ template <class R, bool BRUTE> static TracePlan<R> plan_trace(const DScene<R> &S
     TracePlan<R> p;
     const bool tab = S.n_mats <= LDS_MATS && S.n_lights <= LDS_LIGHTS;
     const bool nrm = S.n_tris <= LDS_TRIS;
-    if (tab && nrm)
-        p.kernel = k_trace<R, BRUTE, true, true>;
-    else if (tab)
-        p.kernel = k_trace<R, BRUTE, true, false>;
-    else if (nrm)
-        p.kernel = k_trace<R, BRUTE, false, true>;
+    if constexpr (sizeof(R) == 8)
+        p.kernel = tab ? (nrm ? k_trace_f64<BRUTE, true, true> : k_trace_f64<BRUTE, true, false>)
+                       : (nrm ? k_trace_f64<BRUTE, false, true> : k_trace_f64<BRUTE, false, false>);
     else
-        p.kernel = k_trace<R, BRUTE, false, false>;
+        p.kernel = tab ? (nrm ? k_trace_f32<BRUTE, true, true> : k_trace_f32<BRUTE, true, false>)
+                       : (nrm ? k_trace_f32<BRUTE, false, true> : k_trace_f32<BRUTE, false, false>);
     int per_cu = blocks_per_cu;
     if (per_cu <= 0)
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, p.kernel, BLOCK, 0));

@@ -7,7 +7,7 @@
 //   primary_ray / k_camera_rays  cPathTracer::GenerateRay        src/tracing/cPathTracer.cpp:129-213
 //   closest_hit / k_raycast .... cAccelStruct::RayCast           src/geometry/cAccelStruct.cpp:28-54
 //   visible / k_vistest ........ cAccelStruct::VisTest           src/geometry/cAccelStruct.cpp:56-87
-//   k_trace .................... the bounce loop of one primary ray, cPathTracer.cpp:555-673:
+//   k_trace_f64 / k_trace_f32 .. the bounce loop of one primary ray, cPathTracer.cpp:555-673:
 //                                RayCast, miss / emitter termination, shading normal, NEE over all
 //                                lights with their VisTest (cBxDF::Sample_Li, src/tracing/cBxDF.cpp:
 //                                16-52), next direction (Sample_f); one (direct, coefficient) record
@@ -173,9 +173,7 @@ __device__ __forceinline__ unsigned long long prefilter_mask(const float *__rest
     // tracer has an atomic (its path-id pool) that it must assume may write anywhere.
     typedef const float __attribute__((address_space(4))) const_float;
     const_float *PQc = (const_float *)(uintptr_t)PQ;
-    for (int r = 0; r < n_recs; r++)
-    {
-        const_float *P = PQc + r * PQ_STRIDE;
+    auto test = [&](const_float *P) -> uint32_t {
         // every field is read up front (one burst of scalar loads) and the tests are combined
         // without short-circuit evaluation: no branches and no load is waited for inside them
         const float nx = P[0], ny = P[1], nz = P[2], pc = P[3];
@@ -197,7 +195,17 @@ __device__ __forceinline__ unsigned long long prefilter_mask(const float *__rest
         const float s = (u + v) - 1.0f, es = eu + ev;
         const bool ka = !(out | (s > es));
         const bool kb = !(out | (s + es < bthr));
-        const uint32_t bits = (ka ? 1u : 0u) | (kb ? 2u : 0u);
+        return (ka ? 1u : 0u) | (kb ? 2u : 0u);
+    };
+    // two records per trip: their scalar loads are issued together, which halves the number of
+    // times the wave waits for the scalar cache
+    for (int r = 0; r < n_recs; r += 2)
+    {
+        const bool two = r + 1 < n_recs;
+        const uint32_t b0 = test(PQc + r * PQ_STRIDE);
+        uint32_t b1 = test(PQc + (two ? r + 1 : r) * PQ_STRIDE);
+        b1 = two ? b1 : 0u;
+        const uint32_t bits = b0 | (b1 << 2);
         if (r < 16)
             mlo |= bits << (2 * r);
         else
@@ -496,14 +504,22 @@ constexpr int LDS_MATS = 48, LDS_LIGHTS = 32, LDS_TRIS = 64;
 // enough to fill the GPU and all waves run dry together.  Every wave leaves the loop once the pool
 // is used up and its 64 lanes are idle.
 // ---------------------------------------------------------------------------------------------
+// 64 prepared camera rays of one wave (direction and RNG key; the origin is the camera position)
+template <class R> struct RayBlock
+{
+    R d[3][64];
+    uint64_t key[64];
+};
+
 template <class R, bool BRUTE, bool TAB, bool NRM>
-__global__ void __launch_bounds__(BLOCK) k_trace(DScene<R> S, DCamera cam, DBatch B, DState<R> st, int chunk)
+__device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &cam, const DBatch &B, const DState<R> &st, int chunk)
 {
     __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : BVH_STACK * BLOCK];
     __shared__ R lds_mats[TAB ? LDS_MATS * MAT_STRIDE : 1];
     __shared__ R lds_lights[TAB ? LDS_LIGHTS * LIGHT_STRIDE : 1];
     __shared__ R lds_nrm[NRM ? LDS_TRIS * 4 : 1];
     __shared__ int lds_tmat[NRM ? LDS_TRIS : 1];
+    __shared__ RayBlock<R> ray_blocks[BLOCK / 64];
     if (TAB)
     {
         for (int k = threadIdx.x; k < S.n_mats * MAT_STRIDE; k += BLOCK)
@@ -529,6 +545,11 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene<R> S, DCamera cam, DBatc
     bool drained = false;       // the pool has no ids left (wave-uniform)
     const uint32_t n_pix = uint32_t(B.n_pix), n_cols = uint32_t(B.n_cols);
     const int depth = B.depth;
+    // camera rays are prepared 64 at a time by the whole wave (full lanes) and handed to idle lanes
+    // from this block: a lane that starts a new path only copies its ray from LDS
+    RayBlock<R> &blk = ray_blocks[threadIdx.x >> 6];
+    uint32_t blk_base = 0, blk_pos = 0, blk_cnt = 0; // wave-uniform: first path id, consumed, size
+    const V3<R> cam_pos = {R(cam.pos[0]), R(cam.pos[1]), R(cam.pos[2])};
 
     bool alive = false;
     V3<R> o = {R(0), R(0), R(0)}, d = {R(0), R(0), R(0)};
@@ -539,38 +560,56 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene<R> S, DCamera cam, DBatc
 
     for (;;)
     {
-        // ---- idle lanes take the next path ids of the wave's range ------------------------------
+        // ---- idle lanes start the next paths ------------------------------------------------------
         const unsigned long long idle = __ballot(!alive);
-        if (idle != 0ull && next == end && !drained)
+        if (idle != 0ull && blk_pos == blk_cnt && !(next == end && drained))
         {
-            uint32_t base = 0;
-            if (lane == 0)
-                base = atomicAdd(st.pool, uint32_t(chunk));
-            base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
-            if (base >= n_paths)
-                drained = true;
-            else
-                next = base, end = n_paths - base < uint32_t(chunk) ? n_paths : base + uint32_t(chunk);
+            if (next == end)
+            {
+                uint32_t base = 0;
+                if (lane == 0)
+                    base = atomicAdd(st.pool, uint32_t(chunk));
+                base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+                if (base >= n_paths)
+                    drained = true;
+                else
+                    next = base, end = n_paths - base < uint32_t(chunk) ? n_paths : base + uint32_t(chunk);
+            }
+            blk_base = next, blk_pos = 0;
+            blk_cnt = end - next < 64u ? end - next : 64u;
+            next += blk_cnt;
+            if (uint32_t(lane) < blk_cnt)
+            {
+                const uint32_t id = blk_base + uint32_t(lane);
+                const uint32_t pix = id % n_pix;
+                const int lr = B.row0 + int(pix / n_cols), col = B.col0 + int(pix % n_cols);
+                const int row = local_row_to_image_row(B, lr);
+                V3<R> ro, rd;
+                primary_ray<R>(cam, col, row, ro, rd);
+                blk.d[0][lane] = rd.x, blk.d[1][lane] = rd.y, blk.d[2][lane] = rd.z;
+                blk.key[lane] = rng_pixel_key(B.seed, uint32_t(row) * uint32_t(B.image_width) + uint32_t(col));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         if (!alive)
         {
-            const uint32_t cand = next + uint32_t(__popcll(idle & lt_mask));
-            if (cand < end)
+            const uint32_t e = blk_pos + uint32_t(__popcll(idle & lt_mask));
+            if (e < blk_cnt)
             {
-                pid = cand;
-                const uint32_t pix = pid % n_pix, s_local = pid / n_pix;
-                const int lr = B.row0 + int(pix / n_cols), col = B.col0 + int(pix % n_cols);
-                const int row = local_row_to_image_row(B, lr);
-                primary_ray<R>(cam, col, row, o, d);
-                key = rng_pixel_key(B.seed, uint32_t(row) * uint32_t(B.image_width) + uint32_t(col));
-                sample = uint32_t(B.sample0) + s_local;
+                pid = blk_base + e;
+                o = cam_pos;
+                d = {blk.d[0][e], blk.d[1][e], blk.d[2][e]};
+                key = blk.key[e];
+                sample = uint32_t(B.sample0) + pid / n_pix;
                 bounce = 0, prim = -1;
                 alive = true;
             }
         }
         {
             const uint32_t taken = uint32_t(__popcll(idle));
-            next = end - next < taken ? end : next + taken;
+            blk_pos = blk_cnt - blk_pos < taken ? blk_cnt : blk_pos + taken;
         }
         if (__ballot(alive) == 0ull)
             break; // pool used up and every lane idle
@@ -700,6 +739,19 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene<R> S, DCamera cam, DBatc
         st.wave_stats[g * 4 + 2] = n_iter;
         st.wave_stats[g * 4 + 3] = n_rec;
     }
+}
+
+// The two precisions are separate kernels because their register budgets differ: the f64 tracer
+// runs 2 waves per SIMD (up to 256 vector registers), the f32 tracer 4 (128).
+template <bool BRUTE, bool TAB, bool NRM>
+__global__ void __launch_bounds__(BLOCK, 2) k_trace_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
+{
+    trace_body<double, BRUTE, TAB, NRM>(S, cam, B, st, chunk);
+}
+template <bool BRUTE, bool TAB, bool NRM>
+__global__ void __launch_bounds__(BLOCK, 4) k_trace_f32(DScene<float> S, DCamera cam, DBatch B, DState<float> st, int chunk)
+{
+    trace_body<float, BRUTE, TAB, NRM>(S, cam, B, st, chunk);
 }
 
 // one thread per path: folds the path's stack records back to front with the per-bounce max-clamp;
