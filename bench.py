@@ -28,7 +28,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, spec
 N_SIMD = 1024                # 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4              # peak engine clock
-VALU_ISSUE_PEAK = N_SIMD * CLOCK_GHZ / 4.0   # G wave64-instructions/s: one per SIMD every 4 cycles
+VALU_ISSUE_PEAK = N_SIMD * CLOCK_GHZ / 2.0   # G wave64 instructions/s: a SIMD-32 issues one every 2 cycles
+VALU_ISSUE_PEAK_F64 = N_SIMD * CLOCK_GHZ / 4.0  # f64 arithmetic runs at half that rate (78.6 TFLOP/s FMA)
 
 
 def algorithmic_bytes(mode, st, n_pix_touched):
@@ -45,10 +46,12 @@ def algorithmic_bytes(mode, st, n_pix_touched):
             "accumulate": paths * 3 * R + n_pix_touched * 48}
 
 
-def valu_calibration(mode):
-    """VALU instructions per 64-lane bounce iteration of k_trace, from the committed PMC profile
-    (SQ_INSTS_VALU / wave iterations of the same workload); None when the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "valu_calibration.json")
+def pmc_calibration(mode):
+    """What only hardware counters can tell, from the committed PMC profile of this same command
+    (tools/make_profiles.py): VALU instructions per 64-lane bounce iteration of the tracer
+    (SQ_INSTS_VALU / wave iterations) and its HBM bytes per launch (FETCH_SIZE, WRITE_SIZE).  None
+    when the profile is absent."""
+    path = os.path.join(ROOT, "profiles", "calibration.json")
     try:
         with open(path) as f:
             return json.load(f).get(mode)
@@ -152,14 +155,19 @@ def main():
                     "note": "k_trace keeps rays, hits and light samples in registers, so its HBM traffic is two "
                             "orders of magnitude below the bandwidth roof by construction; it is bound by vector-ALU "
                             "issue, see valu"}
-        cal = valu_calibration(args.mode)
+        cal = pmc_calibration(args.mode)
+        if cal and dom == "trace" and cal.get("paths_per_launch") == paths_per_step // world // passes:
+            roofline["traffic"] = cal.get("hbm_bytes_per_launch")
+            roofline["traffic_source"] = cal.get("source")
         valu = None
         if cal and ms["trace"] > 0:
             rate = cal["valu_insts_per_wave_iteration"] * ps["wave_iterations"] / (ms["trace"] * 1e-3) / 1e9
             valu = {"kernel": "k_trace", "achieved": round(rate, 1), "peak": VALU_ISSUE_PEAK,
                     "unit": "G wave64 VALU instructions/s", "frac": round(rate / VALU_ISSUE_PEAK, 4),
                     "valu_insts_per_wave_iteration": cal["valu_insts_per_wave_iteration"],
-                    "active_lane_fraction": round(ps["segments"] / (64.0 * max(ps["wave_iterations"], 1)), 4),
+                    "peak_if_all_f64": VALU_ISSUE_PEAK_F64,
+                    "path_lane_fraction": round(ps["segments"] / (64.0 * max(ps["wave_iterations"], 1)), 4),
+                    "active_lanes_per_valu_inst": cal.get("active_lanes_per_valu_inst"),
                     "source": cal.get("source")}
         kernel_ms = {k: round(v, 3) for k, v in ms.items()}
         kernel_ms["other"] = round(ps["ms_other"], 3)
@@ -168,7 +176,7 @@ def main():
         other_mode = "f32" if args.mode == "f64" else "f64"
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        step(mode=other_mode, reduce=False)
+        ost = step(mode=other_mode, reduce=False)
         torch.cuda.synchronize()
         other_value = W * H * args.spp / (time.perf_counter() - t1) / 1e6 if world == 1 else None
 
@@ -189,7 +197,9 @@ def main():
             "mrays_per_s": round((st["segments"] + st["shadow_rays"]) * world * args.steps / dt / 1e6, 1),
             "segments_per_path": round(st["segments"] / st["paths"], 3),
             "roofline": roofline, "valu": valu, "kernels": kernels, "kernel_ms_per_step": kernel_ms,
-            "other_mode": {"dtype": other_mode, "value": None if other_value is None else round(other_value, 3)},
+            "step_stats": {k: int(ps[k]) for k in ("paths", "segments", "shadow_rays", "records", "wave_iterations", "passes")},
+            "other_mode": {"dtype": other_mode, "value": None if other_value is None else round(other_value, 3),
+                           "wave_iterations": int(ost["wave_iterations"]), "passes": int(ost["passes"])},
             "cpu_baseline": cpu, "checks": checks,
         }
     if world > 1:
