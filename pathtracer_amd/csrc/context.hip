@@ -507,17 +507,29 @@ template <class R> struct TracePlan
     bool room_for_finish = false; // the finish kernels can be co-resident with a full tracer grid
 };
 
-template <class R, bool BRUTE> static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu)
+template <class R, bool BRUTE> static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shadow_queue)
 {
     TracePlan<R> p;
     const bool tab = S.n_mats <= LDS_MATS && S.n_lights <= LDS_LIGHTS;
-    const bool nrm = S.n_tris <= LDS_TRIS;
+    // one light, and it is a square light: visibility tests go through the per-wave LDS queue
+    // (all-triangles intersector only: the BVH variant needs its LDS for the traversal stacks)
+    const bool sq1 = BRUTE && S.n_lights == 1 && S.n_square == 1 && shadow_queue;
     if constexpr (sizeof(R) == 8)
-        p.kernel = tab ? (nrm ? k_trace_f64<BRUTE, true, true> : k_trace_f64<BRUTE, true, false>)
-                       : (nrm ? k_trace_f64<BRUTE, false, true> : k_trace_f64<BRUTE, false, false>);
+    {
+        if constexpr (BRUTE)
+            p.kernel = tab ? (sq1 ? k_trace_f64<true, true, true> : k_trace_f64<true, true, false>)
+                           : (sq1 ? k_trace_f64<true, false, true> : k_trace_f64<true, false, false>);
+        else
+            p.kernel = tab ? k_trace_f64<false, true, false> : k_trace_f64<false, false, false>;
+    }
     else
-        p.kernel = tab ? (nrm ? k_trace_f32<BRUTE, true, true> : k_trace_f32<BRUTE, true, false>)
-                       : (nrm ? k_trace_f32<BRUTE, false, true> : k_trace_f32<BRUTE, false, false>);
+    {
+        if constexpr (BRUTE)
+            p.kernel = tab ? (sq1 ? k_trace_f32<true, true, true> : k_trace_f32<true, true, false>)
+                           : (sq1 ? k_trace_f32<true, false, true> : k_trace_f32<true, false, false>);
+        else
+            p.kernel = tab ? k_trace_f32<false, true, false> : k_trace_f32<false, false, false>;
+    }
     int per_cu = blocks_per_cu;
     if (per_cu <= 0)
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, p.kernel, BLOCK, 0));
@@ -659,7 +671,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     // the tracer already works on batch i + 1 in the other state buffer.  (Profiling mode keeps
     // everything on one stream so that the per-kernel times add up.)
     // The grid of the tracer is just large enough to fill the device: its waves are persistent.
-    const TracePlan<R> plan = brute_ ? plan_trace<R, true>(S, trace_blocks_per_cu) : plan_trace<R, false>(S, trace_blocks_per_cu);
+    const TracePlan<R> plan = brute_ ? plan_trace<R, true>(S, trace_blocks_per_cu, shadow_queue) : plan_trace<R, false>(S, trace_blocks_per_cu, shadow_queue);
     const bool overlap = !o.profile && overlap_finish && plan.room_for_finish;
     hipStream_t s2 = overlap ? side_stream() : s;
 

@@ -81,6 +81,8 @@ public:
     int trace_blocks_per_cu = 0;
     // resolve / accumulate of batch i on a side stream while the tracer runs batch i + 1
     bool overlap_finish = true;
+    // single-square-light scenes: park visibility tests in a per-wave LDS queue (full-wave tests)
+    bool shadow_queue = true;
 
     struct Geometry;
     template <class R> struct Impl;

@@ -18,6 +18,8 @@
 #include "bvh.hpp"
 #include "device_math.hpp"
 
+#include <type_traits>
+
 namespace ptx
 {
 
@@ -511,15 +513,33 @@ template <class R> struct RayBlock
     uint64_t key[64];
 };
 
-template <class R, bool BRUTE, bool TAB, bool NRM>
+// Pending visibility tests of one wave (ring buffer in LDS).  Only part of the lanes have a valid
+// light sample in a given bounce; instead of running the visibility test with those lanes alone,
+// they park the segment here and the wave tests 64 parked segments at a time on full lanes.
+template <class R> struct ShadowQueue
+{
+    static constexpr int CAP = 128; // at most 63 left over + 64 new
+    R p1[3][CAP], p2[3][CAP], term[3][CAP];
+    int own[CAP];
+    uint32_t pid[CAP], bounce[CAP];
+};
+struct NoQueue
+{
+};
+
+// SQ1: the scene has exactly one light and it is a square light -- every bounce has at most one
+// visibility test, which goes through the wave's ShadowQueue.  Otherwise the tests run in place.
+template <class R, bool BRUTE, bool TAB, bool SQ1>
 __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &cam, const DBatch &B, const DState<R> &st, int chunk)
 {
+    constexpr bool NRM = BRUTE; // all-triangles intersector = at most 64 triangles: the per-triangle tables fit LDS
     __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : BVH_STACK * BLOCK];
     __shared__ R lds_mats[TAB ? LDS_MATS * MAT_STRIDE : 1];
     __shared__ R lds_lights[TAB ? LDS_LIGHTS * LIGHT_STRIDE : 1];
     __shared__ R lds_nrm[NRM ? LDS_TRIS * 4 : 1];
     __shared__ int lds_tmat[NRM ? LDS_TRIS : 1];
     __shared__ RayBlock<R> ray_blocks[BLOCK / 64];
+    __shared__ typename std::conditional<SQ1, ShadowQueue<R>, NoQueue>::type shadow_queues[BLOCK / 64];
     if (TAB)
     {
         for (int k = threadIdx.x; k < S.n_mats * MAT_STRIDE; k += BLOCK)
@@ -550,6 +570,8 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
     RayBlock<R> &blk = ray_blocks[threadIdx.x >> 6];
     uint32_t blk_base = 0, blk_pos = 0, blk_cnt = 0; // wave-uniform: first path id, consumed, size
     const V3<R> cam_pos = {R(cam.pos[0]), R(cam.pos[1]), R(cam.pos[2])};
+    auto &sq = shadow_queues[threadIdx.x >> 6];
+    uint32_t sq_head = 0, sq_count = 0; // wave-uniform
 
     bool alive = false;
     V3<R> o = {R(0), R(0), R(0)}, d = {R(0), R(0), R(0)};
@@ -557,6 +579,28 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
     int bounce = 0, prim = -1;
     uint64_t key = 0;
     uint32_t n_seg = 0, n_tests = 0, n_iter = 0, n_rec = 0;
+
+    // tests the first n (<= 64) parked segments, one per lane, and writes the direct light of
+    // their bounce records
+    auto drain = [&](uint32_t n) {
+        if constexpr (SQ1)
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (uint32_t(lane) < n)
+            {
+                const uint32_t e = (sq_head + uint32_t(lane)) % ShadowQueue<R>::CAP;
+                const V3<R> a = {sq.p1[0][e], sq.p1[1][e], sq.p1[2][e]};
+                const V3<R> b = {sq.p2[0][e], sq.p2[1][e], sq.p2[2][e]};
+                const bool vis = visible<R, BRUTE>(S, a, b, stk, sq.own[e]);
+                R *rec = st.stack + ((size_t)sq.pid[e] * depth + sq.bounce[e]) * 6;
+                rec[0] = vis ? sq.term[0][e] : R(0), rec[1] = vis ? sq.term[1][e] : R(0), rec[2] = vis ? sq.term[2][e] : R(0);
+            }
+            sq_head = (sq_head + n) % ShadowQueue<R>::CAP;
+            sq_count -= n;
+        }
+    };
 
     for (;;)
     {
@@ -614,117 +658,149 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         if (__ballot(alive) == 0ull)
             break; // pool used up and every lane idle
         n_iter++;
-        if (!alive)
-            continue;
-        n_seg++;
 
         // ---- closest hit and the termination rules (miss / no material -> tail 0; emitter -> Ka) --
+        bool shaded = false;
         V3<R> p = {R(0), R(0), R(0)};
-        const int hit_k = closest_hit<R, BRUTE>(S, o, d, p, stk, prim);
-        int mat_id = -1;
-        if (hit_k >= 0)
-            mat_id = NRM ? lds_tmat[hit_k] : S.tri_mat[hit_k];
-        const int mrow = (mat_id < 0 ? 0 : mat_id) * MAT_STRIDE;
-        const R *m; // the address space (LDS or global) is fixed at compile time
-        if constexpr (TAB)
-            m = lds_mats + mrow;
-        else
-            m = S.mats + mrow;
-        alive = false;
-        if (mat_id < 0)
+        int hit_k = -1;
+        const R *m = nullptr; // the address space (LDS or global) is fixed at compile time
+        if (alive)
         {
-            st.path_state[pid] = uint32_t(bounce) << 16;
-            continue;
-        }
-        if (m[13] != R(0))
-        {
-            st.path_state[pid] = (uint32_t(bounce) << 16) | uint32_t(mat_id + 1);
-            continue;
-        }
-
-        // ---- shading normal: precomputed per triangle when it is flat (its three vertex normals are
-        // equal) or when barycentric normals are off; else interpolated ---------------------------
-        const V3<R> wo = -d;
-        R fn0, fn1, fn2, fn3;
-        if (NRM)
-            fn0 = lds_nrm[hit_k * 4], fn1 = lds_nrm[hit_k * 4 + 1], fn2 = lds_nrm[hit_k * 4 + 2], fn3 = lds_nrm[hit_k * 4 + 3];
-        else
-        {
-            const R *__restrict__ fn = S.tri_nrm + (size_t)hit_k * 4;
-            fn0 = fn[0], fn1 = fn[1], fn2 = fn[2], fn3 = fn[3];
-        }
-        V3<R> nrm = {fn0, fn1, fn2};
-        if (fn3 == R(0))
-        {
-            const int face = S.tri_face[hit_k];
-            const float *__restrict__ vp = S.verts + (size_t)face * 9;
-            const float *__restrict__ np = S.normals + (size_t)face * 9;
-            V3<R> a = {R(vp[0]), R(vp[1]), R(vp[2])}, b = {R(vp[3]), R(vp[4]), R(vp[5])}, c = {R(vp[6]), R(vp[7]), R(vp[8])};
-            V3<R> w = barycentric(p, a, b, c);
-            V3<R> acc = w.x * V3<R>{R(np[0]), R(np[1]), R(np[2])};
-            acc = acc + w.y * V3<R>{R(np[3]), R(np[4]), R(np[5])};
-            acc = acc + w.z * V3<R>{R(np[6]), R(np[7]), R(np[8])};
-            nrm = fast_normalized(acc);
-        }
-
-        // ---- next direction and indirect coefficient ---------------------------------------------
-        V3<R> coef = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
-        if (S.enable_indirect)
-        {
-            const R x1 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 0);
-            const R x2 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 1);
-            bxdf_sample(m, nrm, wo, x1, x2, wi, coef);
-        }
-
-        // ---- NEE over all lights, in order, each square-light sample with its visibility test ----
-        V3<R> direct = {R(0), R(0), R(0)};
-        for (int l = 0; l < S.n_lights; l++)
-        {
-            const R *L;
+            n_seg++;
+            hit_k = closest_hit<R, BRUTE>(S, o, d, p, stk, prim);
+            int mat_id = -1;
+            if (hit_k >= 0)
+                mat_id = NRM ? lds_tmat[hit_k] : S.tri_mat[hit_k];
+            const int mrow = (mat_id < 0 ? 0 : mat_id) * MAT_STRIDE;
             if constexpr (TAB)
-                L = lds_lights + l * LIGHT_STRIDE;
+                m = lds_mats + mrow;
             else
-                L = S.lights + (size_t)l * LIGHT_STRIDE;
-            V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
-            R pdf;
-            const R x1 = rng_draw<R>(key, sample, bounce, 4 * l + 0);
-            const R x2 = rng_draw<R>(key, sample, bounce, 4 * l + 1);
-            const bool square = L[0] == R(0);
-            if (square)
-                pdf = square_light_sample(L, p, x1, x2, ro, rd);
+                m = S.mats + mrow;
+            alive = false;
+            if (mat_id < 0)
+                st.path_state[pid] = uint32_t(bounce) << 16;
+            else if (m[13] != R(0))
+                st.path_state[pid] = (uint32_t(bounce) << 16) | uint32_t(mat_id + 1);
             else
-                pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bounce, 4 * l + 2), ro, rd);
-            if (pdf < R(1e-10))
-                continue;
-            const R cn = dot(nrm, -rd);
-            if (cn < R(0))
-                continue;
-            const V3<R> f = bxdf_eval(m, rd, wo, nrm);
-            const R w = cn / pdf;
-            const V3<R> term = {(L[1] * w) * f.x, (L[2] * w) * f.y, (L[3] * w) * f.z};
-            if (square)
-            {
-                n_tests++;
-                if (!visible<R, BRUTE>(S, ro, p, stk, hit_k))
-                    continue;
-            }
-            direct = direct + term;
+                shaded = true;
         }
 
-        // ---- one stack record per shaded segment --------------------------------------------------
-        R *rec = st.stack + ((size_t)pid * depth + bounce) * 6;
-        rec[0] = direct.x, rec[1] = direct.y, rec[2] = direct.z;
-        rec[3] = coef.x, rec[4] = coef.y, rec[5] = coef.z;
-        n_rec++;
-        if (S.enable_indirect && bounce + 1 < depth)
+        bool park = false; // this lane has a visibility test for the queue
+        V3<R> park_p1 = {R(0), R(0), R(0)}, park_term = {R(0), R(0), R(0)};
+        const uint32_t seg_pid = pid, seg_bounce = uint32_t(bounce);
+        if (shaded)
         {
-            o = p, d = wi, prim = hit_k;
-            bounce++;
-            alive = true;
+            // ---- shading normal: precomputed per triangle when it is flat (its three vertex normals
+            // are equal) or when barycentric normals are off; else interpolated ---------------------
+            const V3<R> wo = -d;
+            R fn0, fn1, fn2, fn3;
+            if (NRM)
+                fn0 = lds_nrm[hit_k * 4], fn1 = lds_nrm[hit_k * 4 + 1], fn2 = lds_nrm[hit_k * 4 + 2], fn3 = lds_nrm[hit_k * 4 + 3];
+            else
+            {
+                const R *__restrict__ fn = S.tri_nrm + (size_t)hit_k * 4;
+                fn0 = fn[0], fn1 = fn[1], fn2 = fn[2], fn3 = fn[3];
+            }
+            V3<R> nrm = {fn0, fn1, fn2};
+            if (fn3 == R(0))
+            {
+                const int face = S.tri_face[hit_k];
+                const float *__restrict__ vp = S.verts + (size_t)face * 9;
+                const float *__restrict__ np = S.normals + (size_t)face * 9;
+                V3<R> a = {R(vp[0]), R(vp[1]), R(vp[2])}, b = {R(vp[3]), R(vp[4]), R(vp[5])}, c = {R(vp[6]), R(vp[7]), R(vp[8])};
+                V3<R> w = barycentric(p, a, b, c);
+                V3<R> acc = w.x * V3<R>{R(np[0]), R(np[1]), R(np[2])};
+                acc = acc + w.y * V3<R>{R(np[3]), R(np[4]), R(np[5])};
+                acc = acc + w.z * V3<R>{R(np[6]), R(np[7]), R(np[8])};
+                nrm = fast_normalized(acc);
+            }
+
+            // ---- next direction and indirect coefficient -----------------------------------------
+            V3<R> coef = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
+            if (S.enable_indirect)
+            {
+                const R x1 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 0);
+                const R x2 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 1);
+                bxdf_sample(m, nrm, wo, x1, x2, wi, coef);
+            }
+
+            // ---- NEE over all lights, in order; a square-light sample needs a visibility test ----
+            V3<R> direct = {R(0), R(0), R(0)};
+            for (int l = 0; l < S.n_lights; l++)
+            {
+                const R *L;
+                if constexpr (TAB)
+                    L = lds_lights + l * LIGHT_STRIDE;
+                else
+                    L = S.lights + (size_t)l * LIGHT_STRIDE;
+                V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
+                R pdf;
+                const R x1 = rng_draw<R>(key, sample, bounce, 4 * l + 0);
+                const R x2 = rng_draw<R>(key, sample, bounce, 4 * l + 1);
+                const bool square = SQ1 || L[0] == R(0);
+                if (square)
+                    pdf = square_light_sample(L, p, x1, x2, ro, rd);
+                else
+                    pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bounce, 4 * l + 2), ro, rd);
+                if (pdf < R(1e-10))
+                    continue;
+                const R cn = dot(nrm, -rd);
+                if (cn < R(0))
+                    continue;
+                const V3<R> f = bxdf_eval(m, rd, wo, nrm);
+                const R w = cn / pdf;
+                const V3<R> term = {(L[1] * w) * f.x, (L[2] * w) * f.y, (L[3] * w) * f.z};
+                if (square)
+                {
+                    n_tests++;
+                    if constexpr (SQ1)
+                    {
+                        park = true, park_p1 = ro, park_term = term;
+                        continue;
+                    }
+                    else if (!visible<R, BRUTE>(S, ro, p, stk, hit_k))
+                        continue;
+                }
+                direct = direct + term;
+            }
+
+            // ---- one stack record per shaded segment (a parked test fills in the direct part) ----
+            R *rec = st.stack + ((size_t)pid * depth + bounce) * 6;
+            if (!park)
+                rec[0] = direct.x, rec[1] = direct.y, rec[2] = direct.z;
+            rec[3] = coef.x, rec[4] = coef.y, rec[5] = coef.z;
+            n_rec++;
+            if (S.enable_indirect && bounce + 1 < depth)
+            {
+                o = p, d = wi, prim = hit_k;
+                bounce++;
+                alive = true;
+            }
+            else
+                st.path_state[pid] = uint32_t(bounce + 1) << 16;
         }
-        else
-            st.path_state[pid] = uint32_t(bounce + 1) << 16;
+
+        if constexpr (SQ1)
+        {
+            // all lanes are back together here: park this bounce's tests, test 64 once they are there
+            const unsigned long long pm = __ballot(park);
+            if (park)
+            {
+                const uint32_t e = (sq_head + sq_count + uint32_t(__popcll(pm & lt_mask))) % ShadowQueue<R>::CAP;
+                sq.p1[0][e] = park_p1.x, sq.p1[1][e] = park_p1.y, sq.p1[2][e] = park_p1.z;
+                sq.p2[0][e] = p.x, sq.p2[1][e] = p.y, sq.p2[2][e] = p.z;
+                sq.term[0][e] = park_term.x, sq.term[1][e] = park_term.y, sq.term[2][e] = park_term.z;
+                sq.own[e] = hit_k;
+                sq.pid[e] = seg_pid, sq.bounce[e] = seg_bounce;
+            }
+            sq_count += uint32_t(__popcll(pm));
+            if (sq_count >= 64u)
+                drain(64u);
+        }
     }
+    if constexpr (SQ1)
+        while (sq_count > 0u)
+            drain(sq_count < 64u ? sq_count : 64u);
     // per-wave statistics (the wave owns its row)
     for (int off = 32; off > 0; off >>= 1)
     {
@@ -743,15 +819,15 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
 
 // The two precisions are separate kernels because their register budgets differ: the f64 tracer
 // runs 2 waves per SIMD (up to 256 vector registers), the f32 tracer 4 (128).
-template <bool BRUTE, bool TAB, bool NRM>
+template <bool BRUTE, bool TAB, bool SQ1>
 __global__ void __launch_bounds__(BLOCK, 2) k_trace_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
 {
-    trace_body<double, BRUTE, TAB, NRM>(S, cam, B, st, chunk);
+    trace_body<double, BRUTE, TAB, SQ1>(S, cam, B, st, chunk);
 }
-template <bool BRUTE, bool TAB, bool NRM>
+template <bool BRUTE, bool TAB, bool SQ1>
 __global__ void __launch_bounds__(BLOCK, 4) k_trace_f32(DScene<float> S, DCamera cam, DBatch B, DState<float> st, int chunk)
 {
-    trace_body<float, BRUTE, TAB, NRM>(S, cam, B, st, chunk);
+    trace_body<float, BRUTE, TAB, SQ1>(S, cam, B, st, chunk);
 }
 
 // one thread per path: folds the path's stack records back to front with the per-bounce max-clamp;
