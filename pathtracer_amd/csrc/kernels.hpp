@@ -494,7 +494,7 @@ __device__ __forceinline__ int lane_id() { return int(threadIdx.x & 63); }
 
 // Small tables -- materials, lights, per-triangle normals and material ids -- are read from LDS
 // copies when they fit.  TAB: materials and lights fit; NRM: the per-triangle tables fit too.
-constexpr int LDS_MATS = 48, LDS_LIGHTS = 32, LDS_TRIS = 64;
+constexpr int LDS_MATS = 32, LDS_LIGHTS = 32, LDS_TRIS = 64;
 
 // ---------------------------------------------------------------------------------------------
 // persistent tracer: every LANE carries one path in registers from its camera ray to its end --
@@ -515,13 +515,15 @@ template <class R> struct RayBlock
 
 // Pending visibility tests of one wave (ring buffer in LDS).  Only part of the lanes have a valid
 // light sample in a given bounce; instead of running the visibility test with those lanes alone,
-// they park the segment here and the wave tests 64 parked segments at a time on full lanes.
+// they park the segment here and the wave tests 64 parked segments at a time on full lanes.  The
+// light term itself is already in the bounce record; a blocked segment zeroes it afterwards.
 template <class R> struct ShadowQueue
 {
     static constexpr int CAP = 128; // at most 63 left over + 64 new
-    R p1[3][CAP], p2[3][CAP], term[3][CAP];
-    int own[CAP];
-    uint32_t pid[CAP], bounce[CAP];
+    R xi[2][CAP];                   // the two draws the light sample point is a function of
+    R p2[3][CAP];                   // shaded point
+    int own[CAP];                   // triangle the shaded point lies on
+    uint32_t pid[CAP], bounce[CAP]; // which bounce record the result belongs to
 };
 struct NoQueue
 {
@@ -535,7 +537,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
     constexpr bool NRM = BRUTE; // all-triangles intersector = at most 64 triangles: the per-triangle tables fit LDS
     __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : BVH_STACK * BLOCK];
     __shared__ R lds_mats[TAB ? LDS_MATS * MAT_STRIDE : 1];
-    __shared__ R lds_lights[TAB ? LDS_LIGHTS * LIGHT_STRIDE : 1];
+    __shared__ R lds_lights[TAB ? (SQ1 ? 1 : LDS_LIGHTS) * LIGHT_STRIDE : 1];
     __shared__ R lds_nrm[NRM ? LDS_TRIS * 4 : 1];
     __shared__ int lds_tmat[NRM ? LDS_TRIS : 1];
     __shared__ RayBlock<R> ray_blocks[BLOCK / 64];
@@ -580,8 +582,8 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
     uint64_t key = 0;
     uint32_t n_seg = 0, n_tests = 0, n_iter = 0, n_rec = 0;
 
-    // tests the first n (<= 64) parked segments, one per lane, and writes the direct light of
-    // their bounce records
+    // tests the first n (<= 64) parked segments, one per lane, and removes the direct light of
+    // the blocked ones from their bounce records
     auto drain = [&](uint32_t n) {
         if constexpr (SQ1)
         {
@@ -591,11 +593,19 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             if (uint32_t(lane) < n)
             {
                 const uint32_t e = (sq_head + uint32_t(lane)) % ShadowQueue<R>::CAP;
-                const V3<R> a = {sq.p1[0][e], sq.p1[1][e], sq.p1[2][e]};
+                const R *L0;
+                if constexpr (TAB)
+                    L0 = lds_lights;
+                else
+                    L0 = S.lights;
+                const V3<R> a = square_light_point(L0, sq.xi[0][e], sq.xi[1][e]); // same point as at shading time
                 const V3<R> b = {sq.p2[0][e], sq.p2[1][e], sq.p2[2][e]};
-                const bool vis = visible<R, BRUTE>(S, a, b, stk, sq.own[e]);
-                R *rec = st.stack + ((size_t)sq.pid[e] * depth + sq.bounce[e]) * 6;
-                rec[0] = vis ? sq.term[0][e] : R(0), rec[1] = vis ? sq.term[1][e] : R(0), rec[2] = vis ? sq.term[2][e] : R(0);
+                if (!visible<R, BRUTE>(S, a, b, stk, sq.own[e]))
+                {
+                    // same wave, later in program order than the store of the term: this one wins
+                    R *rec = st.stack + ((size_t)sq.pid[e] * depth + sq.bounce[e]) * 6;
+                    rec[0] = R(0), rec[1] = R(0), rec[2] = R(0);
+                }
             }
             sq_head = (sq_head + n) % ShadowQueue<R>::CAP;
             sq_count -= n;
@@ -686,7 +696,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         }
 
         bool park = false; // this lane has a visibility test for the queue
-        V3<R> park_p1 = {R(0), R(0), R(0)}, park_term = {R(0), R(0), R(0)};
+        R park_x1 = R(0), park_x2 = R(0);
         const uint32_t seg_pid = pid, seg_bounce = uint32_t(bounce);
         if (shaded)
         {
@@ -754,20 +764,16 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 {
                     n_tests++;
                     if constexpr (SQ1)
-                    {
-                        park = true, park_p1 = ro, park_term = term;
-                        continue;
-                    }
+                        park = true, park_x1 = x1, park_x2 = x2; // the term counts unless the test fails later
                     else if (!visible<R, BRUTE>(S, ro, p, stk, hit_k))
                         continue;
                 }
                 direct = direct + term;
             }
 
-            // ---- one stack record per shaded segment (a parked test fills in the direct part) ----
+            // ---- one stack record per shaded segment -------------------------------------------------
             R *rec = st.stack + ((size_t)pid * depth + bounce) * 6;
-            if (!park)
-                rec[0] = direct.x, rec[1] = direct.y, rec[2] = direct.z;
+            rec[0] = direct.x, rec[1] = direct.y, rec[2] = direct.z;
             rec[3] = coef.x, rec[4] = coef.y, rec[5] = coef.z;
             n_rec++;
             if (S.enable_indirect && bounce + 1 < depth)
@@ -787,9 +793,8 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             if (park)
             {
                 const uint32_t e = (sq_head + sq_count + uint32_t(__popcll(pm & lt_mask))) % ShadowQueue<R>::CAP;
-                sq.p1[0][e] = park_p1.x, sq.p1[1][e] = park_p1.y, sq.p1[2][e] = park_p1.z;
+                sq.xi[0][e] = park_x1, sq.xi[1][e] = park_x2;
                 sq.p2[0][e] = p.x, sq.p2[1][e] = p.y, sq.p2[2][e] = p.z;
-                sq.term[0][e] = park_term.x, sq.term[1][e] = park_term.y, sq.term[2][e] = park_term.z;
                 sq.own[e] = hit_k;
                 sq.pid[e] = seg_pid, sq.bounce[e] = seg_bounce;
             }
@@ -818,9 +823,10 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
 }
 
 // The two precisions are separate kernels because their register budgets differ: the f64 tracer
-// runs 2 waves per SIMD (up to 256 vector registers), the f32 tracer 4 (128).
+// runs 2 waves per SIMD (up to 256 vector registers) -- 3 (168 registers) when the visibility
+// tests are queued, which takes their live range out of the shading code -- the f32 tracer 4 (128).
 template <bool BRUTE, bool TAB, bool SQ1>
-__global__ void __launch_bounds__(BLOCK, 2) k_trace_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
+__global__ void __launch_bounds__(BLOCK, SQ1 ? 3 : 2) k_trace_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
 {
     trace_body<double, BRUTE, TAB, SQ1>(S, cam, B, st, chunk);
 }
