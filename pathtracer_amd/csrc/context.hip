@@ -254,7 +254,7 @@ template <class R> struct Context::Impl
 struct Context::Geometry
 {
     DeviceBuffer tri_face, tri_mat, verts, normals, mat_ids, nodes;
-    DeviceBuffer tri_pq, rec_tri, tri_rec; // plane records of the all-triangles intersector
+    DeviceBuffer tri_pq, rec_tri, tri_rec, rec_block; // plane records of the all-triangles intersector
     int n_recs = 0;
 };
 
@@ -357,6 +357,23 @@ void Context::build_accel(const Scene &sc)
     upload(geo_->tri_pq, pr.rec, s);
     upload(geo_->rec_tri, pr.rec_tri, s);
     upload(geo_->tri_rec, pr.tri_rec, s);
+    {
+        // potential blockers per record towards light 0 (used when it is the scene's only light and square)
+        std::vector<uint32_t> blk(32, 0xFFFFFFFFu);
+        if (brute_ && sc.lights.size() == 1 && sc.lights[0].type == 0)
+        {
+            const Light &L = sc.lights[0];
+            double corners[4][3];
+            for (int c3 = 0; c3 < 3; c3++)
+            {
+                const double e10 = L.p[1][c3] - L.p[0][c3], e21 = L.p[2][c3] - L.p[1][c3];
+                corners[0][c3] = L.p[0][c3], corners[1][c3] = L.p[0][c3] + e10;
+                corners[2][c3] = L.p[0][c3] + e10 + e21, corners[3][c3] = L.p[0][c3] + e21;
+            }
+            blk = blocker_masks(sc.verts.data(), pr, corners);
+        }
+        upload(geo_->rec_block, blk, s);
+    }
     geo_->n_recs = pr.n_recs;
     f64_->build_tables(sc, bvh_, brute_, s);
     f32_->build_tables(sc, bvh_, brute_, s);
@@ -380,6 +397,7 @@ template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::
     S.tri_pq = static_cast<const float *>(g.tri_pq.p);
     S.rec_tri = static_cast<const int32_t *>(g.rec_tri.p);
     S.tri_rec = static_cast<const int32_t *>(g.tri_rec.p);
+    S.rec_block = static_cast<const uint32_t *>(g.rec_block.p);
     S.tri_face = static_cast<const int32_t *>(g.tri_face.p);
     S.verts = static_cast<const float *>(g.verts.p);
     S.normals = static_cast<const float *>(g.normals.p);

@@ -35,6 +35,7 @@ template <class R> struct DScene
     const float *tri_pq;       // [n_recs][32] f32 plane records (all-triangles intersector)
     const int32_t *rec_tri;    // [64] candidate bit -> triangle, -1: none
     const int32_t *tri_rec;    // [n_tris] triangle -> plane record
+    const uint32_t *rec_block; // [32] records that can block a segment from record i to light 0 (one-square-light scenes)
     const int32_t *tri_face;   // intersector order -> face id
     const float *verts;        // [n_faces][9]  by face id
     const float *normals;      // [n_faces][9]
@@ -138,6 +139,7 @@ template <class R> struct BruteLds
     int rec_tri[2 * BRUTE_MAX_RECS];    // mask bit -> triangle (-1: none)
     int tri_rec[BRUTE_MAX_TRIS];        // triangle -> plane record
     float rec_n[BRUTE_MAX_RECS * 4];    // unit normals of the plane records
+    uint32_t rec_block[BRUTE_MAX_RECS]; // potential blockers between record i and light 0
 };
 constexpr int LDS_WORDS_BRUTE = int(sizeof(BruteLds<double>) / 4);
 
@@ -155,6 +157,8 @@ template <class R, bool BRUTE> __device__ __forceinline__ int *intersector_scrat
             L->tri_rec[k] = S.tri_rec[k];
         for (int k = threadIdx.x; k < S.n_recs * 4; k += BLOCK)
             L->rec_n[k] = S.tri_pq[(k >> 2) * PQ_STRIDE + (k & 3)];
+        for (int k = threadIdx.x; k < BRUTE_MAX_RECS; k += BLOCK)
+            L->rec_block[k] = S.rec_block[k];
         __syncthreads();
         return lds; // shared tables: same pointer for every lane
     }
@@ -163,7 +167,7 @@ template <class R, bool BRUTE> __device__ __forceinline__ int *intersector_scrat
 
 template <class R>
 __device__ __forceinline__ unsigned long long prefilter_mask(const float *__restrict__ PQ, int n_recs, V3<R> o, V3<R> d, float tmin,
-                                                             float tmax)
+                                                             float tmax, uint32_t rec_mask = 0xFFFFFFFFu)
 {
 #pragma clang fp contract(fast) // rounding differences are inside the error bounds of the records
     const float ox = float(o.x), oy = float(o.y), oz = float(o.z);
@@ -199,15 +203,15 @@ __device__ __forceinline__ unsigned long long prefilter_mask(const float *__rest
         const bool kb = !(out | (s + es < bthr));
         return (ka ? 1u : 0u) | (kb ? 2u : 0u);
     };
-    // two records per trip: their scalar loads are issued together, which halves the number of
-    // times the wave waits for the scalar cache
-    for (int r = 0; r < n_recs; r += 2)
+    // only the records named by rec_mask (wave-uniform) are visited
+    uint32_t todo = uint32_t(__builtin_amdgcn_readfirstlane(int(rec_mask)));
+    if (n_recs < 32)
+        todo &= (1u << n_recs) - 1u;
+    while (todo)
     {
-        const bool two = r + 1 < n_recs;
-        const uint32_t b0 = test(PQc + r * PQ_STRIDE);
-        uint32_t b1 = test(PQc + (two ? r + 1 : r) * PQ_STRIDE);
-        b1 = two ? b1 : 0u;
-        const uint32_t bits = b0 | (b1 << 2);
+        const int r = __builtin_ctz(todo);
+        todo &= todo - 1u;
+        const uint32_t bits = test(PQc + r * PQ_STRIDE);
         if (r < 16)
             mlo |= bits << (2 * r);
         else
@@ -332,7 +336,8 @@ __device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d,
 }
 
 // segment visibility p1 -> p2: blocked iff some triangle has self_eps < t < |p1 - p2| - self_eps
-template <class R, bool BRUTE> __device__ __forceinline__ bool visible(const DScene<R> &S, V3<R> p1, V3<R> p2, int *stk, int skip = -1)
+template <class R, bool BRUTE>
+__device__ __forceinline__ bool visible(const DScene<R> &S, V3<R> p1, V3<R> p2, int *stk, int skip = -1, uint32_t rec_mask = 0xFFFFFFFFu)
 {
     const R self_eps = Consts<R>::self_eps;
     R dist = norm(p1 - p2);
@@ -342,7 +347,7 @@ template <class R, bool BRUTE> __device__ __forceinline__ bool visible(const DSc
         const BruteLds<R> *L = reinterpret_cast<const BruteLds<R> *>(stk);
         // blockers have self_eps < t < dist - self_eps: drop what surely lies outside (0.9 self_eps, dist)
         const float far = float(dist) * 1.00001f + 1e-30f;
-        unsigned long long mask = prefilter_mask(S.tri_pq, S.n_recs, p1, dir, float(self_eps) * 0.9f, far);
+        unsigned long long mask = prefilter_mask(S.tri_pq, S.n_recs, p1, dir, float(self_eps) * 0.9f, far, rec_mask);
         // p2 lies on triangle `skip`: as seen from p1 its plane is met at distance ~dist, which is
         // not a blocker either
         mask = drop_own_plane(mask, L, skip, dir);
@@ -590,9 +595,22 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // records that can block any of this pass's segments: union over the lanes of the
+            // blocker sets of the records their shaded points lie on
+            const uint32_t e = (sq_head + uint32_t(lane)) % ShadowQueue<R>::CAP;
+            uint32_t blockers = 0u;
+            if constexpr (BRUTE)
+            {
+                const BruteLds<R> *T = reinterpret_cast<const BruteLds<R> *>(stk);
+                if (uint32_t(lane) < n)
+                    blockers = T->rec_block[T->tri_rec[sq.own[e]]];
+                for (int off = 32; off > 0; off >>= 1)
+                    blockers |= uint32_t(__shfl_xor(int(blockers), off, 64));
+            }
+            else
+                blockers = 0xFFFFFFFFu;
             if (uint32_t(lane) < n)
             {
-                const uint32_t e = (sq_head + uint32_t(lane)) % ShadowQueue<R>::CAP;
                 const R *L0;
                 if constexpr (TAB)
                     L0 = lds_lights;
@@ -600,7 +618,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                     L0 = S.lights;
                 const V3<R> a = square_light_point(L0, sq.xi[0][e], sq.xi[1][e]); // same point as at shading time
                 const V3<R> b = {sq.p2[0][e], sq.p2[1][e], sq.p2[2][e]};
-                if (!visible<R, BRUTE>(S, a, b, stk, sq.own[e]))
+                if (!visible<R, BRUTE>(S, a, b, stk, sq.own[e], blockers))
                 {
                     // same wave, later in program order than the store of the term: this one wins
                     R *rec = st.stack + ((size_t)sq.pid[e] * depth + sq.bounce[e]) * 6;

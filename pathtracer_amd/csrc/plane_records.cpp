@@ -199,4 +199,105 @@ void build_plane_records(const float *verts, int n_tris, PlaneRecords &out)
     }
 }
 
+std::vector<uint32_t> blocker_masks(const float *verts, const PlaneRecords &pr, const double light[4][3])
+{
+    const int n = pr.n_recs;
+    std::vector<uint32_t> masks(32, 0xFFFFFFFFu);
+    if (n > 32)
+        return masks;
+    // vertices of every record (3 or 4) and the plane of its first triangle, in double
+    struct RecGeo
+    {
+        double v[4][3];
+        int nv = 0;
+        double nrm[3] = {0, 0, 0}, c = 0;
+        bool plane_ok = false;
+    };
+    std::vector<RecGeo> geo(n);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int r = 0; r < n; r++)
+    {
+        RecGeo &g = geo[r];
+        for (int half = 0; half < 2; half++)
+        {
+            const int t = pr.rec_tri[2 * r + half];
+            if (t < 0)
+                continue;
+            for (int k = 0; k < 3; k++)
+            {
+                const float *p = verts + static_cast<size_t>(t) * 9 + 3 * k;
+                bool seen = false;
+                for (int q = 0; q < g.nv; q++)
+                    seen = seen || (g.v[q][0] == p[0] && g.v[q][1] == p[1] && g.v[q][2] == p[2]);
+                if (!seen && g.nv < 4)
+                {
+                    for (int c3 = 0; c3 < 3; c3++)
+                        g.v[g.nv][c3] = p[c3];
+                    g.nv++;
+                }
+            }
+        }
+        const int t0 = pr.rec_tri[2 * r];
+        if (t0 >= 0)
+        {
+            const float *p = verts + static_cast<size_t>(t0) * 9;
+            double e1[3], e2[3];
+            for (int c3 = 0; c3 < 3; c3++)
+                e1[c3] = double(p[3 + c3]) - double(p[c3]), e2[c3] = double(p[6 + c3]) - double(p[c3]);
+            double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+            const double len = std::sqrt(nx * nx + ny * ny + nz * nz);
+            if (len > 0 && std::isfinite(len))
+            {
+                g.nrm[0] = nx / len, g.nrm[1] = ny / len, g.nrm[2] = nz / len;
+                g.c = g.nrm[0] * p[0] + g.nrm[1] * p[1] + g.nrm[2] * p[2];
+                g.plane_ok = true;
+            }
+        }
+        for (int q = 0; q < g.nv; q++)
+            for (int c3 = 0; c3 < 3; c3++)
+                lo[c3] = std::min(lo[c3], g.v[q][c3]), hi[c3] = std::max(hi[c3], g.v[q][c3]);
+    }
+    for (int q = 0; q < 4; q++)
+        for (int c3 = 0; c3 < 3; c3++)
+        {
+            if (!std::isfinite(light[q][c3]))
+                return masks;
+            lo[c3] = std::min(lo[c3], light[q][c3]), hi[c3] = std::max(hi[c3], light[q][c3]);
+        }
+    const double diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+    // An end point may sit on the wrong side of the plane by rounding, by no more than
+    // delta = 1e-12 diag (thousands of ulps of the largest coordinate).  With the other end `clear`
+    // away from the plane, the crossing then lies within delta * diag / clear of that end point;
+    // the visibility test ignores whatever lies within 1e-6 (absolute) of an end point, and
+    // clear = 1e-5 diag^2 keeps the crossing ten times closer than that.
+    const double tol = 1e-9 * diag, clear = 1e-5 * diag * diag;
+    for (int i = 0; i < n; i++)
+    {
+        uint32_t m = 0;
+        for (int j = 0; j < n; j++)
+        {
+            const RecGeo &pj = geo[j];
+            bool can_block = true;
+            if (pj.plane_ok && geo[i].nv >= 3) // j == i too: a segment leaving record i towards a light clear of
+                                               // its plane does not meet that plane again
+            {
+                for (int sgn = -1; sgn <= 1 && can_block; sgn += 2)
+                {
+                    double min_i = 1e300, min_l = 1e300;
+                    for (int q = 0; q < geo[i].nv; q++)
+                        min_i = std::min(min_i, sgn * (pj.nrm[0] * geo[i].v[q][0] + pj.nrm[1] * geo[i].v[q][1] + pj.nrm[2] * geo[i].v[q][2] - pj.c));
+                    for (int q = 0; q < 4; q++)
+                        min_l = std::min(min_l, sgn * (pj.nrm[0] * light[q][0] + pj.nrm[1] * light[q][1] + pj.nrm[2] * light[q][2] - pj.c));
+                    if (min_i >= -tol && min_l >= -tol && std::max(min_i, min_l) >= clear)
+                        can_block = false;
+                }
+            }
+            if (can_block)
+                m |= 1u << j;
+        }
+        masks[i] = m;
+    }
+    return masks;
+}
+
 } // namespace ptx

@@ -22,4 +22,11 @@ struct PlaneRecords
 // verts: [n_tris][9] float positions by face id.  Triangles stay in face order.
 void build_plane_records(const float *verts, int n_tris, PlaneRecords &out);
 
+// Which records can possibly block a segment between a point of record i and a point of the
+// parallelogram `light` (4 corners, [4][3])?  Returns one bit mask per record i (bit j: record j is
+// a potential blocker).  Record j is ruled out only if its supporting plane has all of record i and
+// all of the light in one closed half space, at least one of the two well clear of the plane: a
+// segment between them then never crosses the plane in its interior.
+std::vector<uint32_t> blocker_masks(const float *verts, const PlaneRecords &pr, const double light[4][3]);
+
 } // namespace ptx
