@@ -256,6 +256,7 @@ struct Context::Geometry
     DeviceBuffer tri_face, tri_mat, verts, normals, mat_ids, nodes;
     DeviceBuffer tri_pq, rec_tri, tri_rec, rec_block; // plane records of the all-triangles intersector
     int n_recs = 0;
+    float smax = 0.f;
 };
 
 Context::Context(int device) : device_(device)
@@ -375,6 +376,7 @@ void Context::build_accel(const Scene &sc)
         upload(geo_->rec_block, blk, s);
     }
     geo_->n_recs = pr.n_recs;
+    geo_->smax = pr.smax;
     f64_->build_tables(sc, bvh_, brute_, s);
     f32_->build_tables(sc, bvh_, brute_, s);
     HIP_CHECK(hipStreamSynchronize(s));
@@ -393,6 +395,8 @@ template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::
     S.enable_indirect = sc.enable_indirect;
     S.enable_bary = sc.enable_bary_normal && sc.has_normals;
     S.n_recs = g.n_recs;
+    S.pq_smax = g.smax;
+    S.pad_[0] = S.pad_[1] = S.pad_[2] = 0.f;
     S.tri_pre = static_cast<const R *>(tri_pre);
     S.tri_pq = static_cast<const float *>(g.tri_pq.p);
     S.rec_tri = static_cast<const int32_t *>(g.rec_tri.p);

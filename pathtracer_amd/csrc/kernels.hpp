@@ -31,6 +31,7 @@ template <class R> struct DScene
 {
     int n_tris, n_mats, n_lights, n_square;
     int brute, enable_indirect, enable_bary, n_recs;
+    float pq_smax, pad_[3];    // largest |c| of the plane records
     const R *tri_pre;          // [n_tris][12] in intersector order: p1, p1-p2, p1-p3, cofactors
     const float *tri_pq;       // [n_recs][32] f32 plane records (all-triangles intersector)
     const int32_t *rec_tri;    // [64] candidate bit -> triangle, -1: none
@@ -118,15 +119,16 @@ template <class R> __device__ __forceinline__ R box_entry(const float *lo, const
 // from LDS, with the reference's tie rule (equal distance -> lowest face id), so hits, distances
 // and tie-breaking are identical to testing every triangle exactly.
 //
-// Record (32 floats):
-//   0-2 unit normal n, 3 c = n.P0,
-//   4-6 a, 7 a.P0   (u = a.X - a.P0),   8-10 b, 11 b.P0   (v = b.X - b.P0),
-//   12,13 centre and half width of the u range, 14,15 of the v range (A alone: [0,1]; with B: the
-//   box around both), 16,17 Eu, Eu0, 18,19 Ev, Ev0, 20 Et, 21 |c|, 22 0 (with B) or +inf (A alone).
-// With r = 1 / |n.d|, To = max|o| and W = (1.75 To + |c|) r^2 the computed t, u, v are within
-// Et W, Eu W + Eu0, Ev W + Ev0 of their exact values (Eu = 64 eps |a|_1, Eu0 = 16 eps |a.P0|,
-// Et = 32 eps; first-order bounds are 13, 24 and 5 eps, including the rounding of the ray and of the
-// record to f32).
+// Record (32 floats), with u = a.(X - P0), v = b.(X - P0) the coordinates of the plane point X in
+// the (e1, e2) basis:
+//   0-2 unit normal n, 3 c = n.P0,   4-6 a,   8-10 b,
+//   12,13 centre of the admissible range of a.X (= u + a.P0) and its half width + E0,
+//   14,15 the same for b.X (A alone: u, v in [0,1]; with B: the box around both),
+//   16 E, 17 2 E0, 18 1 + a.P0 + b.P0, 20 Et, 22 0 (with B) or +inf (A alone).
+// With r = 1 / |n.d|, To = max|o| and W = (1.75 To + max_records |c|) r^2 the computed t, u, v
+// are within Et W and E W + E0 of their exact values (E = 64 eps max(|a|_1, |b|_1),
+// E0 = 16 eps (max(|a.P0|, |b.P0|) + 1), Et = 32 eps; first-order bounds are 13, 24 and 5 eps,
+// including the rounding of the ray and of the record to f32).
 // ---------------------------------------------------------------------------------------------
 constexpr int PQ_STRIDE = 32;
 constexpr int BRUTE_MAX_TRIS = 64; // candidate mask is one 64-bit word ...
@@ -166,52 +168,52 @@ template <class R, bool BRUTE> __device__ __forceinline__ int *intersector_scrat
 }
 
 template <class R>
-__device__ __forceinline__ unsigned long long prefilter_mask(const float *__restrict__ PQ, int n_recs, V3<R> o, V3<R> d, float tmin,
-                                                             float tmax, uint32_t rec_mask = 0xFFFFFFFFu)
+__device__ __forceinline__ unsigned long long prefilter_mask(const float *__restrict__ PQ, int n_recs, float smax, V3<R> o, V3<R> d,
+                                                             float tmin, float tmax, uint32_t rec_mask = 0xFFFFFFFFu)
 {
 #pragma clang fp contract(fast) // rounding differences are inside the error bounds of the records
     const float ox = float(o.x), oy = float(o.y), oz = float(o.z);
     const float dx = float(d.x), dy = float(d.y), dz = float(d.z);
-    const float To = 1.75f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
+    const float Tmax = 1.75f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + smax;
     uint32_t mlo = 0, mhi = 0;
+    // only the records named by rec_mask (wave-uniform) are visited
+    uint32_t todo = uint32_t(__builtin_amdgcn_readfirstlane(int(rec_mask)));
+    if (n_recs < 32)
+        todo &= (1u << n_recs) - 1u;
     // The records never change while a kernel runs.  Reading them through the constant address
     // space tells the compiler so: the wave-uniform loads stay scalar-cache loads even though the
     // tracer has an atomic (its path-id pool) that it must assume may write anywhere.
     typedef const float __attribute__((address_space(4))) const_float;
     const_float *PQc = (const_float *)(uintptr_t)PQ;
-    auto test = [&](const_float *P) -> uint32_t {
-        // every field is read up front (one burst of scalar loads) and the tests are combined
-        // without short-circuit evaluation: no branches and no load is waited for inside them
-        const float nx = P[0], ny = P[1], nz = P[2], pc = P[3];
-        const float ax = P[4], ay = P[5], az = P[6], a0 = P[7];
-        const float bx = P[8], by = P[9], bz = P[10], b0 = P[11];
-        const float uc = P[12], uh = P[13], vc = P[14], vh = P[15];
-        const float Eu = P[16], Eu0 = P[17], Ev = P[18], Ev0 = P[19], Et = P[20], Sc = P[21], bthr = P[22];
-        const float nd = nx * dx + ny * dy + nz * dz;
-        const float no = pc - (nx * ox + ny * oy + nz * oz);
-        const float rr = __builtin_amdgcn_rcpf(nd);
-        const float t = no * rr;
-        const float W = (To + Sc) * (rr * rr);
-        const float X = fmaf(t, dx, ox), Y = fmaf(t, dy, oy), Z = fmaf(t, dz, oz);
-        const float u = fmaf(ax, X, fmaf(ay, Y, fmaf(az, Z, -a0)));
-        const float v = fmaf(bx, X, fmaf(by, Y, fmaf(bz, Z, -b0)));
-        const float eu = fmaf(Eu, W, Eu0), ev = fmaf(Ev, W, Ev0), et = Et * W;
-        // all comparisons are false on NaN / infinity soup, which keeps the candidate
-        const bool out = (fabsf(u - uc) > uh + eu) | (fabsf(v - vc) > vh + ev) | (t + et < tmin) | (t - et > tmax);
-        const float s = (u + v) - 1.0f, es = eu + ev;
-        const bool ka = !(out | (s > es));
-        const bool kb = !(out | (s + es < bthr));
-        return (ka ? 1u : 0u) | (kb ? 2u : 0u);
-    };
-    // only the records named by rec_mask (wave-uniform) are visited
-    uint32_t todo = uint32_t(__builtin_amdgcn_readfirstlane(int(rec_mask)));
-    if (n_recs < 32)
-        todo &= (1u << n_recs) - 1u;
+    // every field is read up front (one burst of scalar loads); the comparisons are false on NaN /
+    // infinity soup, which keeps the candidate, and are combined without short-circuit evaluation
+    // (no branches).  Every vector instruction below has at most one scalar operand.
     while (todo)
     {
         const int r = __builtin_ctz(todo);
         todo &= todo - 1u;
-        const uint32_t bits = test(PQc + r * PQ_STRIDE);
+        const_float *P = PQc + r * PQ_STRIDE;
+        const float nx = P[0], ny = P[1], nz = P[2], pc = P[3];
+        const float ax = P[4], ay = P[5], az = P[6], bx = P[8], by = P[9], bz = P[10];
+        const float uc = P[12], uh = P[13], vc = P[14], vh = P[15];
+        const float E = P[16], E02 = P[17], k1 = P[18], Et = P[20], bthr = P[22];
+        const float nd = nx * dx + ny * dy + nz * dz;
+        const float no = pc - (nx * ox + ny * oy + nz * oz);
+        const float rr = __builtin_amdgcn_rcpf(nd);
+        const float t = no * rr;
+        const float W = Tmax * (rr * rr);
+        const float X = fmaf(t, dx, ox), Y = fmaf(t, dy, oy), Z = fmaf(t, dz, oz);
+        const float u = ax * X + ay * Y + az * Z; // u + a.P0
+        const float v = bx * X + by * Y + bz * Z; // v + b.P0
+        float We = E * W;
+        asm volatile("" : "+v"(We)); // keep the product in a register: folded into the three sums below it
+                                     // would need a second scalar operand (an extra move) in each
+        const float et = Et * W;
+        const bool out = (fabsf(u - uc) > uh + We) | (fabsf(v - vc) > vh + We) | (t + et < tmin) | (t - et > tmax);
+        const float s = (u + v) - k1, es = fmaf(We, 2.0f, E02);
+        const bool ka = !(out | (s > es));
+        const bool kb = !(out | (s + es < bthr));
+        const uint32_t bits = (ka ? 1u : 0u) | (kb ? 2u : 0u);
         if (r < 16)
             mlo |= bits << (2 * r);
         else
@@ -247,7 +249,7 @@ __device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d,
     if (BRUTE)
     {
         const BruteLds<R> *L = reinterpret_cast<const BruteLds<R> *>(stk);
-        unsigned long long mask = prefilter_mask(S.tri_pq, S.n_recs, o, d, float(self_eps) * 0.9f, __builtin_inff());
+        unsigned long long mask = prefilter_mask(S.tri_pq, S.n_recs, S.pq_smax, o, d, float(self_eps) * 0.9f, __builtin_inff());
         mask = drop_own_plane(mask, L, skip, d);
         while (mask)
         {
@@ -347,7 +349,7 @@ __device__ __forceinline__ bool visible(const DScene<R> &S, V3<R> p1, V3<R> p2, 
         const BruteLds<R> *L = reinterpret_cast<const BruteLds<R> *>(stk);
         // blockers have self_eps < t < dist - self_eps: drop what surely lies outside (0.9 self_eps, dist)
         const float far = float(dist) * 1.00001f + 1e-30f;
-        unsigned long long mask = prefilter_mask(S.tri_pq, S.n_recs, p1, dir, float(self_eps) * 0.9f, far, rec_mask);
+        unsigned long long mask = prefilter_mask(S.tri_pq, S.n_recs, S.pq_smax, p1, dir, float(self_eps) * 0.9f, far, rec_mask);
         // p2 lies on triangle `skip`: as seen from p1 its plane is met at distance ~dist, which is
         // not a blocker either
         mask = drop_own_plane(mask, L, skip, dir);

@@ -182,20 +182,24 @@ void build_plane_records(const float *verts, int n_tris, PlaneRecords &out)
             o[22] = 0.f;
             out.n_pairs++;
         }
+        const double a1 = std::fabs(a[0]) + std::fabs(a[1]) + std::fabs(a[2]), b1 = std::fabs(b[0]) + std::fabs(b[1]) + std::fabs(b[2]);
+        const double E = 64 * eps * std::max(a1, b1), E0 = 16 * eps * (std::max(std::fabs(a0), std::fabs(b0)) + 1);
         for (int c = 0; c < 3; c++)
         {
             o[c] = static_cast<float>(n[c] * inv_len);
             o[4 + c] = static_cast<float>(a[c]);
             o[8 + c] = static_cast<float>(b[c]);
         }
-        o[3] = static_cast<float>(c0), o[7] = static_cast<float>(a0), o[11] = static_cast<float>(b0);
-        o[12] = static_cast<float>(0.5 * (ulo + uhi)), o[13] = round_up(0.5 * (uhi - ulo) * (1 + 4 * eps) + 4 * eps);
-        o[14] = static_cast<float>(0.5 * (vlo + vhi)), o[15] = round_up(0.5 * (vhi - vlo) * (1 + 4 * eps) + 4 * eps);
-        const double a1 = std::fabs(a[0]) + std::fabs(a[1]) + std::fabs(a[2]), b1 = std::fabs(b[0]) + std::fabs(b[1]) + std::fabs(b[2]);
-        o[16] = round_up(64 * eps * a1), o[17] = round_up(16 * eps * (std::fabs(a0) + 1));
-        o[18] = round_up(64 * eps * b1), o[19] = round_up(16 * eps * (std::fabs(b0) + 1));
+        o[3] = static_cast<float>(c0);
+        // the device compares a.X (not a.X - a.P0) with the range, so the offsets move into the
+        // centres; half widths carry the constant part of the error bound
+        o[12] = static_cast<float>(0.5 * (ulo + uhi) + a0), o[13] = round_up(0.5 * (uhi - ulo) * (1 + 4 * eps) + 4 * eps * (1 + std::fabs(a0)) + E0);
+        o[14] = static_cast<float>(0.5 * (vlo + vhi) + b0), o[15] = round_up(0.5 * (vhi - vlo) * (1 + 4 * eps) + 4 * eps * (1 + std::fabs(b0)) + E0);
+        o[16] = round_up(E), o[17] = round_up(2 * E0 + 8 * eps * (1 + std::fabs(a0) + std::fabs(b0)));
+        o[18] = static_cast<float>(1.0 + a0 + b0);
         o[20] = round_up(32 * eps);
         o[21] = round_up(std::fabs(c0));
+        out.smax = std::max(out.smax, o[21]);
     }
 }
 

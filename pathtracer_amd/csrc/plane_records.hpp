@@ -17,6 +17,7 @@ struct PlaneRecords
     std::vector<int32_t> tri_rec;  // [n_tris] triangle -> record
     int n_recs = 0;
     int n_pairs = 0;
+    float smax = 0.f;              // largest |c| (plane offset) of the records, rounded up
 };
 
 // verts: [n_tris][9] float positions by face id.  Triangles stay in face order.
