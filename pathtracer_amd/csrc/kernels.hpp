@@ -140,7 +140,7 @@ template <class R> struct BruteLds
     R tri[BRUTE_MAX_TRIS * 12];         // exact-test records, by triangle
     int rec_tri[2 * BRUTE_MAX_RECS];    // mask bit -> triangle (-1: none)
     int tri_rec[BRUTE_MAX_TRIS];        // triangle -> plane record
-    float rec_n[BRUTE_MAX_RECS * 4];    // unit normals of the plane records
+    float rec_n[BRUTE_MAX_RECS * 4];    // unit normal and plane offset of the plane records
     uint32_t rec_block[BRUTE_MAX_RECS]; // potential blockers between record i and light 0
 };
 constexpr int LDS_WORDS_BRUTE = int(sizeof(BruteLds<double>) / 4);
@@ -158,7 +158,7 @@ template <class R, bool BRUTE> __device__ __forceinline__ int *intersector_scrat
         for (int k = threadIdx.x; k < S.n_tris; k += BLOCK)
             L->tri_rec[k] = S.tri_rec[k];
         for (int k = threadIdx.x; k < S.n_recs * 4; k += BLOCK)
-            L->rec_n[k] = S.tri_pq[(k >> 2) * PQ_STRIDE + (k & 3)];
+            L->rec_n[k] = S.tri_pq[(k >> 2) * PQ_STRIDE + (k & 3)]; // n and c = n.P0
         for (int k = threadIdx.x; k < BRUTE_MAX_RECS; k += BLOCK)
             L->rec_block[k] = S.rec_block[k];
         __syncthreads();
@@ -167,15 +167,21 @@ template <class R, bool BRUTE> __device__ __forceinline__ int *intersector_scrat
     return lds + threadIdx.x; // BVH: stack slot [level][lane]
 }
 
-template <class R>
+constexpr float PQ_ET = 32.0f / 16777216.0f; // Et of every record (32 eps)
+
+// NEAREST: also report the candidate record with the smallest positive lower bound of its hit
+// distance (near_rec, -1: none) -- the closest-hit search tests it first.
+template <bool NEAREST, class R>
 __device__ __forceinline__ unsigned long long prefilter_mask(const float *__restrict__ PQ, int n_recs, float smax, V3<R> o, V3<R> d,
-                                                             float tmin, float tmax, uint32_t rec_mask = 0xFFFFFFFFu)
+                                                             float tmin, float tmax, uint32_t rec_mask, int &near_rec)
 {
 #pragma clang fp contract(fast) // rounding differences are inside the error bounds of the records
     const float ox = float(o.x), oy = float(o.y), oz = float(o.z);
     const float dx = float(d.x), dy = float(d.y), dz = float(d.z);
     const float Tmax = 1.75f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + smax;
     uint32_t mlo = 0, mhi = 0;
+    float near_t = __builtin_inff();
+    near_rec = -1;
     // only the records named by rec_mask (wave-uniform) are visited
     uint32_t todo = uint32_t(__builtin_amdgcn_readfirstlane(int(rec_mask)));
     if (n_recs < 32)
@@ -214,6 +220,13 @@ __device__ __forceinline__ unsigned long long prefilter_mask(const float *__rest
         const bool ka = !(out | (s > es));
         const bool kb = !(out | (s + es < bthr));
         const uint32_t bits = (ka ? 1u : 0u) | (kb ? 2u : 0u);
+        if (NEAREST)
+        {
+            const float tlo = t - et;
+            const bool nearer = (ka | kb) & (tlo > 0.0f) & (tlo < near_t);
+            near_t = nearer ? tlo : near_t;
+            near_rec = nearer ? r : near_rec;
+        }
         if (r < 16)
             mlo |= bits << (2 * r);
         else
@@ -249,12 +262,11 @@ __device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d,
     if (BRUTE)
     {
         const BruteLds<R> *L = reinterpret_cast<const BruteLds<R> *>(stk);
-        unsigned long long mask = prefilter_mask(S.tri_pq, S.n_recs, S.pq_smax, o, d, float(self_eps) * 0.9f, __builtin_inff());
+        int near_rec;
+        unsigned long long mask =
+            prefilter_mask<true>(S.tri_pq, S.n_recs, S.pq_smax, o, d, float(self_eps) * 0.9f, __builtin_inff(), 0xFFFFFFFFu, near_rec);
         mask = drop_own_plane(mask, L, skip, d);
-        while (mask)
-        {
-            const int bit = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
+        auto exact = [&](int bit) {
             const int f = L->rec_tri[bit];
             R t;
             if (f >= 0 && tri_test(L->tri + f * 12, o, d, t))
@@ -269,6 +281,45 @@ __device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d,
                     pt = p;
                 }
             }
+        };
+        // 1. the record that looks nearest in f32 goes first ...
+        if (near_rec >= 0)
+        {
+            unsigned long long first = mask & (3ull << (2 * near_rec));
+            mask &= ~first;
+            while (first)
+            {
+                exact(__ffsll((long long)first) - 1);
+                first &= first - 1;
+            }
+        }
+        // 2. ... then every other candidate whose f32 distance interval lies wholly beyond that hit
+        // is dropped (it can neither win nor tie); the intervals are recomputed from the LDS copy
+        // of the plane normals, with the error bound of the prefilter
+        if (target >= 0)
+        {
+            const float ox = float(o.x), oy = float(o.y), oz = float(o.z), dx = float(d.x), dy = float(d.y), dz = float(d.z);
+            const float Tmax = 1.75f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + S.pq_smax;
+            const float bound = float(best) * 1.000001f + 1e-30f;
+            unsigned long long rest = mask;
+            while (rest)
+            {
+                const int bit = __ffsll((long long)rest) - 1;
+                rest &= rest - 1;
+                const float *N = L->rec_n + (bit >> 1) * 4;
+                const float nd = N[0] * dx + N[1] * dy + N[2] * dz;
+                const float no = N[3] - (N[0] * ox + N[1] * oy + N[2] * oz);
+                const float rr = __builtin_amdgcn_rcpf(nd);
+                const float tlo = no * rr - PQ_ET * (Tmax * (rr * rr));
+                if (tlo > bound) // false on NaN: the candidate stays
+                    mask &= ~(1ull << bit);
+            }
+        }
+        // 3. what is left gets the exact test
+        while (mask)
+        {
+            exact(__ffsll((long long)mask) - 1);
+            mask &= mask - 1;
         }
         return target;
     }
@@ -349,7 +400,8 @@ __device__ __forceinline__ bool visible(const DScene<R> &S, V3<R> p1, V3<R> p2, 
         const BruteLds<R> *L = reinterpret_cast<const BruteLds<R> *>(stk);
         // blockers have self_eps < t < dist - self_eps: drop what surely lies outside (0.9 self_eps, dist)
         const float far = float(dist) * 1.00001f + 1e-30f;
-        unsigned long long mask = prefilter_mask(S.tri_pq, S.n_recs, S.pq_smax, p1, dir, float(self_eps) * 0.9f, far, rec_mask);
+        int unused_rec;
+        unsigned long long mask = prefilter_mask<false>(S.tri_pq, S.n_recs, S.pq_smax, p1, dir, float(self_eps) * 0.9f, far, rec_mask, unused_rec);
         // p2 lies on triangle `skip`: as seen from p1 its plane is met at distance ~dist, which is
         // not a blocker either
         mask = drop_own_plane(mask, L, skip, dir);

@@ -197,7 +197,7 @@ void build_plane_records(const float *verts, int n_tris, PlaneRecords &out)
         o[14] = static_cast<float>(0.5 * (vlo + vhi) + b0), o[15] = round_up(0.5 * (vhi - vlo) * (1 + 4 * eps) + 4 * eps * (1 + std::fabs(b0)) + E0);
         o[16] = round_up(E), o[17] = round_up(2 * E0 + 8 * eps * (1 + std::fabs(a0) + std::fabs(b0)));
         o[18] = static_cast<float>(1.0 + a0 + b0);
-        o[20] = round_up(32 * eps);
+        o[20] = 32.0f / 16777216.0f; // = PQ_ET of the device code
         o[21] = round_up(std::fabs(c0));
         out.smax = std::max(out.smax, o[21]);
     }
