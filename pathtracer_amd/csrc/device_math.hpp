@@ -30,9 +30,14 @@ template <class R> __device__ __forceinline__ V3<R> operator-(V3<R> a) { return 
 template <class R> __device__ __forceinline__ V3<R> operator*(V3<R> a, R s) { return {a.x * s, a.y * s, a.z * s}; }
 template <class R> __device__ __forceinline__ V3<R> operator*(R s, V3<R> a) { return {s * a.x, s * a.y, s * a.z}; }
 template <class R> __device__ __forceinline__ V3<R> operator/(V3<R> a, R s) { return {a.x / s, a.y / s, a.z / s}; }
-template <class R> __device__ __forceinline__ R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class R> __device__ __forceinline__ R dot(V3<R> a, V3<R> b)
+{
+#pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
 template <class R> __device__ __forceinline__ V3<R> cross(V3<R> a, V3<R> b)
 {
+#pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 template <class R> __device__ __forceinline__ R norm(V3<R> a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
@@ -50,15 +55,19 @@ template <class R> __device__ __forceinline__ V3<R> normalized(V3<R> a)
 template <class R> __device__ __forceinline__ bool has_nan(V3<R> a) { return isnan(a.x) || isnan(a.y) || isnan(a.z); }
 
 // Shading-side helpers.  The intersector keeps the reference's exact operation order (its accept /
-// reject decisions and distances are compared bit for bit with the CPU restatement); the shading
-// math below uses algebraically identical but cheaper forms (reciprocal square roots, no inverse
-// trigonometry), which moves results by a few ulps only.
+// reject decisions and distances are compared bit for bit with the CPU restatement; this
+// translation unit is built with -ffp-contract=off).  The shading math uses algebraically
+// identical but cheaper forms (reciprocal square roots, no inverse trigonometry) and, function by
+// function, allows fused multiply-adds (#pragma clang fp contract(fast)), which moves results by a
+// few ulps only.  The vector operators, norm, normalized, tri_test and square_light_point stay
+// unfused: they feed the intersector.
 __device__ __forceinline__ double rsqrt_(double x) { return rsqrt(x); }
 __device__ __forceinline__ float rsqrt_(float x) { return rsqrtf(x); }
 __device__ __forceinline__ void sincospi_(double x, double &s, double &c) { sincospi(x, &s, &c); }
 __device__ __forceinline__ void sincospi_(float x, float &s, float &c) { sincospif(x, &s, &c); }
 template <class R> __device__ __forceinline__ V3<R> fast_normalized(V3<R> a)
 {
+#pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
     R z = a.x * a.x + a.y * a.y + a.z * a.z;
     R k = z > R(0) ? rsqrt_(z) : R(1);
     return {a.x * k, a.y * k, a.z * k};
@@ -139,6 +148,7 @@ template <class R> __device__ __forceinline__ bool tri_test(const R *__restrict_
 // ---------------------------------------------------------------------------------------------
 template <class R> __device__ __forceinline__ V3<R> reflect(V3<R> n, V3<R> in)
 {
+#pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
     R k = R(2) * dot(n, -in);
     return k * n + in;
 }
@@ -146,6 +156,7 @@ template <class R> __device__ __forceinline__ V3<R> reflect(V3<R> n, V3<R> in)
 // NaN components on total internal reflection
 template <class R> __device__ __forceinline__ V3<R> refract(V3<R> n, V3<R> in, R ni)
 {
+#pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
     if (dot(n, in) > R(0))
     {
         n = -n;
@@ -160,6 +171,7 @@ template <class R> __device__ __forceinline__ V3<R> refract(V3<R> n, V3<R> in, R
 // 3x3 inverse times vector, cofactors of column 0 / determinant along column 0 (row-major m)
 template <class R> __device__ __forceinline__ V3<R> solve3(const R *m, V3<R> p)
 {
+#pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
     R c00 = m[4] * m[8] - m[5] * m[7];
     R c10 = m[7] * m[2] - m[8] * m[1];
     R c20 = m[1] * m[5] - m[2] * m[4];
@@ -202,6 +214,7 @@ template <class R> __device__ __forceinline__ V3<R> barycentric(V3<R> p, V3<R> a
 // form with cos = n.y, sin = |(n.x, n.z)|, axis (n.z, 0, -n.x) / sin.
 template <class R> __device__ __forceinline__ V3<R> sample_hemisphere(V3<R> n, R xi1, R xi2)
 {
+#pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
     R ct = R(1) - xi1;
     R st = sqrt(xi1 * (R(2) - xi1));
     R sp, cp;
@@ -236,6 +249,7 @@ __device__ __attribute__((noinline)) float pow_outlined(float x, float y) { retu
 
 template <class R> __device__ __forceinline__ V3<R> brdf_eval(const R *__restrict__ m, V3<R> wi, V3<R> wo, V3<R> n)
 {
+#pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
     const R pi = Consts<R>::pi;
     R ca = dot(reflect(n, wi), wo);
     R ns = m[10];
@@ -247,6 +261,7 @@ template <class R> __device__ __forceinline__ V3<R> brdf_eval(const R *__restric
 
 template <class R> __device__ __forceinline__ V3<R> bsdf_eval(const R *__restrict__ m, V3<R> wi, V3<R> wo, V3<R> n)
 {
+#pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
     V3<R> ideal = refract(n, wi, R(1) / m[9]);
     if (has_nan(ideal))
         ideal = reflect(n, wi);
@@ -266,6 +281,7 @@ template <class R> __device__ __forceinline__ V3<R> bxdf_eval(const R *__restric
 template <class R>
 __device__ __forceinline__ void bxdf_sample(const R *__restrict__ m, V3<R> n, V3<R> wo, R xi1, R xi2, V3<R> &wi, V3<R> &coef)
 {
+#pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
     const R pi = Consts<R>::pi;
     if (m[12] == R(0))
     {
@@ -302,6 +318,7 @@ template <class R> __device__ __forceinline__ V3<R> square_light_point(const R *
 template <class R>
 __device__ __forceinline__ R square_light_sample(const R *__restrict__ L, V3<R> ref, R xi1, R xi2, V3<R> &ro, V3<R> &rd)
 {
+#pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
     V3<R> N = {L[13], L[14], L[15]};
     R area = L[16];
     V3<R> s = square_light_point(L, xi1, xi2);
@@ -323,6 +340,7 @@ __device__ __forceinline__ R square_light_sample(const R *__restrict__ L, V3<R> 
 template <class R>
 __device__ __forceinline__ R sphere_light_sample(const R *__restrict__ L, V3<R> ref, R xi1, R xi2, R xi3, V3<R> &ro, V3<R> &rd)
 {
+#pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
     const R pi = Consts<R>::pi;
     V3<R> C = {L[4], L[5], L[6]};
     R rad = L[7];
