@@ -35,14 +35,13 @@ VALU_ISSUE_PEAK_F64 = N_SIMD * CLOCK_GHZ / 4.0  # f64 arithmetic runs at half th
 def algorithmic_bytes(mode, st, n_pix_touched):
     """HBM bytes each kernel must move for the work of one step (scene tables excluded: they are a
     few KB read through the scalar cache / LDS).  R = size of the scalar type.
-      k_trace ...... one 6-scalar (direct, coefficient) record per shaded segment + one state word per path;
-                     rays, hits and NEE samples never leave the registers
-      k_resolve .... reads those records and state words, writes 3 scalars per path
+      k_trace ...... writes one 6-scalar (direct, coefficient) record per shaded segment and 3 result scalars
+                     per path; rays, hits and NEE samples never leave the registers, and the records are read
+                     back for the resolve pass by the wave that wrote them (from L2)
       k_accumulate . reads 3 scalars per path, reads + writes the f64 rgb sum of every pixel it touches"""
     R = 8 if mode == "f64" else 4
     rec, paths = st["records"], st["paths"]
-    return {"trace": rec * 6 * R + paths * 4,
-            "resolve": rec * 6 * R + paths * (4 + 3 * R),
+    return {"trace": rec * 6 * R + paths * 3 * R,
             "accumulate": paths * 3 * R + n_pix_touched * 48}
 
 
@@ -135,7 +134,7 @@ def main():
         # on the render stream (same workload, same stream; not part of the timed region above)
         ps = step(profile=True, reduce=False)   # rank 0 only: no collective in here
         torch.cuda.synchronize()
-        ms = {"trace": ps["ms_trace"], "resolve": ps["ms_resolve"], "accumulate": ps["ms_accumulate"]}
+        ms = {"trace": ps["ms_trace"], "accumulate": ps["ms_accumulate"]}
         passes = int(ps["passes"])
         ab = algorithmic_bytes(args.mode, ps, W * H * passes)
         dom = max(ms, key=ms.get)

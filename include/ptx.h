@@ -77,7 +77,7 @@ typedef struct ptx_stats
                                (64 * wave_iterations) is its active-lane fraction               */
     uint64_t records;       /* (direct, coefficient) records written = shaded segments           */
     double ms_total;        /* device time of the call, HIP events on the context's stream       */
-    double ms_trace, ms_resolve, ms_accumulate, ms_other; /* per-kernel device time (profiling
+    double ms_trace, ms_accumulate, ms_other; /* per-kernel device time (profiling
                                mode only, otherwise 0)                                           */
 } ptx_stats;
 

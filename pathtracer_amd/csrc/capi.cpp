@@ -403,7 +403,7 @@ int ptx_render(ptx_context *c, const ptx_render_opts *o, double *rgb_sum, int32_
         stats->wave_iterations = st.wave_iterations;
         stats->records = st.records;
         stats->ms_total = st.ms_total;
-        stats->ms_trace = st.ms_class[0], stats->ms_resolve = st.ms_class[1], stats->ms_accumulate = st.ms_class[2];
+        stats->ms_trace = st.ms_class[0], stats->ms_accumulate = st.ms_class[2];
         stats->ms_other = st.ms_class[3];
     }
     PTX_CATCH

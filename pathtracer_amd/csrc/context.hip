@@ -2,9 +2,9 @@
 //
 // Replaces cPathTracer::Init / Process / RayTracing (src/tracing/cPathTracer.cpp:20-57, 65-86,
 // 517-553 of the reference): instead of an OpenMP loop over rows, a batch of paths (pixels x
-// samples) is traced by one persistent kernel in which every lane carries one path at a time, a
-// resolve kernel folds each path's (direct, coefficient) records back to front, and an accumulate
-// kernel adds the per-sample results to the per-pixel sums in sample order.
+// samples) is traced by one persistent kernel in which every lane carries one path at a time and
+// finished paths are resolved (their (direct, coefficient) records folded back to front) 64 at a
+// time, and an accumulate kernel adds the per-sample results to the per-pixel sums in sample order.
 #include "context.hpp"
 #include "kernels.hpp"
 #include "plane_records.hpp"
@@ -223,7 +223,6 @@ template <class R> struct Context::Impl
             return off;
         };
         const size_t o_stack = take(N * 6 * sizeof(R) * depth);
-        const size_t o_ps = take(N * 4);
         const size_t o_res = take(N * 3 * sizeof(R));
         const size_t o_ws = take(static_cast<size_t>(MAX_TRACE_WAVES) * 4 * sizeof(unsigned long long));
         const size_t o_pool = take(sizeof(unsigned int));
@@ -238,7 +237,6 @@ template <class R> struct Context::Impl
             state_mem[k].alloc(total);
             char *base = static_cast<char *>(state_mem[k].p);
             st[k].stack = reinterpret_cast<R *>(base + o_stack);
-            st[k].path_state = reinterpret_cast<uint32_t *>(base + o_ps);
             st[k].result = reinterpret_cast<R *>(base + o_res);
             st[k].wave_stats = reinterpret_cast<unsigned long long *>(base + o_ws);
             st[k].stats = static_cast<unsigned long long *>(totals.p);
@@ -561,7 +559,7 @@ template <class R, bool BRUTE> static TracePlan<R> plan_trace(const DScene<R> &S
     // their waves still fits
     hipFuncAttributes ft, fr;
     HIP_CHECK(hipFuncGetAttributes(&ft, reinterpret_cast<const void *>(p.kernel)));
-    HIP_CHECK(hipFuncGetAttributes(&fr, reinterpret_cast<const void *>(k_resolve<R>)));
+    HIP_CHECK(hipFuncGetAttributes(&fr, reinterpret_cast<const void *>(k_accumulate<R>)));
     auto granule = [](int regs) { return (std::max(regs, 1) + 7) / 8 * 8; };
     const int waves_per_simd = p.blocks_per_cu * (BLOCK / 64) / 4;
     p.room_for_finish = 512 - waves_per_simd * granule(ft.numRegs) >= granule(fr.numRegs);
@@ -580,14 +578,11 @@ static void launch_trace(const TracePlan<R> &plan, const DScene<R> &S, const DCa
     HIP_CHECK(hipGetLastError());
 }
 
-// resolve + accumulate + statistics of one traced batch
+// accumulate + statistics of one traced batch
 template <class R>
 static void launch_finish(const DScene<R> &S, const DBatch &B, const DState<R> &st, double *sum, hipStream_t s, RenderTimers *tm)
 {
     const dim3 block(BLOCK);
-    if (tm)
-        tm->mark(s, RenderTimers::RESOLVE);
-    hipLaunchKernelGGL((k_resolve<R>), dim3(blocks_for(B.n_paths)), block, 0, s, S, B, st);
     if (tm)
         tm->mark(s, RenderTimers::ACCUMULATE);
     hipLaunchKernelGGL((k_accumulate<R>), dim3(blocks_for(B.n_pix)), block, 0, s, B, st, sum);

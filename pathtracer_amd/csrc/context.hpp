@@ -30,7 +30,7 @@ struct RenderStats
 {
     uint64_t paths = 0, segments = 0, shadow_rays = 0, passes = 0, wave_iterations = 0, records = 0;
     double ms_total = 0;
-    double ms_class[4] = {0, 0, 0, 0}; // trace, resolve, accumulate, other
+    double ms_class[4] = {0, 0, 0, 0}; // trace, (unused), accumulate, other
 };
 
 // per-kernel-class timing with HIP events on the render stream (profiling mode only)

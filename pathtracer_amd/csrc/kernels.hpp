@@ -12,8 +12,8 @@
 //                                lights with their VisTest (cBxDF::Sample_Li, src/tracing/cBxDF.cpp:
 //                                16-52), next direction (Sample_f); one (direct, coefficient) record
 //                                per bounce
-//   k_resolve / k_accumulate ... back-to-front combine with the per-bounce max-clamp, and the
-//                                per-pixel average in sample order, cPathTracer.cpp:679-692
+//   resolve (in trace_body) .... back-to-front combine with the per-bounce max-clamp,
+//   k_accumulate                 and the per-pixel average in sample order, cPathTracer.cpp:679-692
 #pragma once
 #include "bvh.hpp"
 #include "device_math.hpp"
@@ -82,8 +82,7 @@ __device__ __forceinline__ int local_row_to_image_row(const DBatch &b, int lr)
 template <class R> struct DState
 {
     R *stack;                       // [N][depth][6] by pid: direct rgb, coefficient rgb of every bounce
-    uint32_t *path_state;           // [N] by pid: (len << 16) | (tail material + 1)
-    R *result;                      // [3][N] by pid: resolved per-sample radiance
+    R *result;                      // [3][N] by pid: resolved per-sample radiance (written by the tracer)
     unsigned long long *wave_stats; // [n_waves][4] segments, shadow tests, wave iterations, records
     unsigned long long *stats;      // [8] totals (filled by k_reduce_stats)
     unsigned int *pool;             // next unassigned path id of the current batch
@@ -581,11 +580,20 @@ template <class R> struct ShadowQueue
     static constexpr int CAP = 128; // at most 63 left over + 64 new
     R xi[2][CAP];                   // the two draws the light sample point is a function of
     R p2[3][CAP];                   // shaded point
-    int own[CAP];                   // triangle the shaded point lies on
-    uint32_t pid[CAP], bounce[CAP]; // which bounce record the result belongs to
+    uint32_t own_bounce[CAP];       // (triangle the shaded point lies on << 16) | bounce
+    uint32_t pid[CAP];              // own_bounce, pid: which bounce record the result belongs to
 };
 struct NoQueue
 {
+};
+
+// Finished paths of one wave waiting for their resolve pass (ring buffer in LDS): path id,
+// (record count << 16) | (tail material + 1), and how many visibility tests the wave had parked
+// when the path ended -- once that many have been tested, no test of this path is pending.
+struct DoneQueue
+{
+    static constexpr int CAP = 128;
+    uint32_t pid[CAP], state[CAP], need[CAP];
 };
 
 // SQ1: the scene has exactly one light and it is a square light -- every bounce has at most one
@@ -601,6 +609,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
     __shared__ int lds_tmat[NRM ? LDS_TRIS : 1];
     __shared__ RayBlock<R> ray_blocks[BLOCK / 64];
     __shared__ typename std::conditional<SQ1, ShadowQueue<R>, NoQueue>::type shadow_queues[BLOCK / 64];
+    __shared__ DoneQueue done_queues[BLOCK / 64];
     if (TAB)
     {
         for (int k = threadIdx.x; k < S.n_mats * MAT_STRIDE; k += BLOCK)
@@ -633,6 +642,9 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
     const V3<R> cam_pos = {R(cam.pos[0]), R(cam.pos[1]), R(cam.pos[2])};
     auto &sq = shadow_queues[threadIdx.x >> 6];
     uint32_t sq_head = 0, sq_count = 0; // wave-uniform
+    uint32_t sq_pushed = 0, sq_drained = 0; // running totals (wave-uniform, wrap around)
+    DoneQueue &dq = done_queues[threadIdx.x >> 6];
+    uint32_t dq_head = 0, dq_count = 0; // wave-uniform
 
     bool alive = false;
     V3<R> o = {R(0), R(0), R(0)}, d = {R(0), R(0), R(0)};
@@ -657,7 +669,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             {
                 const BruteLds<R> *T = reinterpret_cast<const BruteLds<R> *>(stk);
                 if (uint32_t(lane) < n)
-                    blockers = T->rec_block[T->tri_rec[sq.own[e]]];
+                    blockers = T->rec_block[T->tri_rec[sq.own_bounce[e] >> 16]];
                 for (int off = 32; off > 0; off >>= 1)
                     blockers |= uint32_t(__shfl_xor(int(blockers), off, 64));
             }
@@ -672,16 +684,100 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                     L0 = S.lights;
                 const V3<R> a = square_light_point(L0, sq.xi[0][e], sq.xi[1][e]); // same point as at shading time
                 const V3<R> b = {sq.p2[0][e], sq.p2[1][e], sq.p2[2][e]};
-                if (!visible<R, BRUTE>(S, a, b, stk, sq.own[e], blockers))
+                const uint32_t ob = sq.own_bounce[e];
+                if (!visible<R, BRUTE>(S, a, b, stk, int(ob >> 16), blockers))
                 {
                     // same wave, later in program order than the store of the term: this one wins
-                    R *rec = st.stack + ((size_t)sq.pid[e] * depth + sq.bounce[e]) * 6;
+                    R *rec = st.stack + ((size_t)sq.pid[e] * depth + (ob & 0xffffu)) * 6;
                     rec[0] = R(0), rec[1] = R(0), rec[2] = R(0);
                 }
             }
             sq_head = (sq_head + n) % ShadowQueue<R>::CAP;
             sq_count -= n;
+            sq_drained += n;
         }
+    };
+
+    // folds the bounce records of the first n (<= 64) finished paths back to front with the
+    // per-bounce max-clamp (cPathTracer.cpp:679-692), one path per lane, and stores the per-sample
+    // results.  The records were written by this wave a few iterations ago, so they come from L2.
+    auto resolve = [&](uint32_t n) {
+#pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
+        // a parked visibility test may still have to zero the direct light of one of these paths
+        if constexpr (SQ1)
+        {
+            const uint32_t need_n = uint32_t(__builtin_amdgcn_readfirstlane(int(dq.need[(dq_head + n - 1u) % DoneQueue::CAP])));
+            while (int32_t(sq_drained - need_n) < 0)
+                drain(sq_count < 64u ? sq_count : 64u);
+        }
+        // the records were stored by other lanes of this same wave: waiting for those stores is
+        // enough, a compute unit's vector cache is coherent for its own waves (workgroup scope)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t e = (dq_head + uint32_t(lane)) % DoneQueue::CAP;
+        const bool mine = uint32_t(lane) < n;
+        const uint32_t rp = mine ? dq.pid[e] : 0u, rs = mine ? dq.state[e] : 0u;
+        const int len = int(rs >> 16), tm = int(rs & 0xffffu);
+        R fr = R(0), fg = R(0), fb = R(0);
+        if (tm)
+        {
+            const R *tmat;
+            if constexpr (TAB)
+                tmat = lds_mats + (tm - 1) * MAT_STRIDE;
+            else
+                tmat = S.mats + (size_t)(tm - 1) * MAT_STRIDE;
+            fr = tmat[0], fg = tmat[1], fb = tmat[2];
+        }
+        int wlen = len; // longest stack of the wave: the loop below has a wave-uniform trip count
+        for (int off = 32; off > 0; off >>= 1)
+            wlen = max(wlen, __shfl_xor(wlen, off, 64));
+        const R *rec = st.stack + (size_t)rp * depth * 6;
+        // four levels per trip: their loads are issued together, so the wave waits for the memory
+        // system once per four bounces instead of once per bounce
+        constexpr int G = 4;
+        for (int top = wlen - 1; top >= 0; top -= G)
+        {
+            R q[G][6];
+#pragma unroll
+            for (int k = 0; k < G; k++)
+            {
+                const int i = top - k;
+                const bool on = i >= 0 && i < len;
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+                    q[k][c] = on ? rec[(on ? i : 0) * 6 + c] : R(0);
+            }
+#pragma unroll
+            for (int k = 0; k < G; k++)
+            {
+                const int i = top - k;
+                if (i >= 0 && i < len)
+                {
+                    fr = q[k][0] + q[k][3] * fr;
+                    fg = q[k][1] + q[k][4] * fg;
+                    fb = q[k][2] + q[k][5] * fb;
+                    R mx = fr;
+                    if (fg > mx)
+                        mx = fg;
+                    if (fb > mx)
+                        mx = fb;
+                    if (R(0) > mx)
+                        mx = R(0);
+                    if (mx > R(1))
+                    {
+                        // one reciprocal instead of the reference's three divisions: results move by
+                        // an ulp at most, like the rest of the shading arithmetic
+                        const R inv = R(1) / mx;
+                        fr *= inv, fg *= inv, fb *= inv;
+                    }
+                }
+            }
+        }
+        if (mine)
+            st.result[rp] = fr, st.result[st.N + rp] = fg, st.result[2 * st.N + rp] = fb;
+        dq_head = (dq_head + n) % DoneQueue::CAP;
+        dq_count -= n;
     };
 
     for (;;)
@@ -742,7 +838,8 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         n_iter++;
 
         // ---- closest hit and the termination rules (miss / no material -> tail 0; emitter -> Ka) --
-        bool shaded = false;
+        bool shaded = false, finished = false; // finished: this lane's path ended in this iteration
+        uint32_t fin_state = 0;
         V3<R> p = {R(0), R(0), R(0)};
         int hit_k = -1;
         const R *m = nullptr; // the address space (LDS or global) is fixed at compile time
@@ -760,9 +857,9 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 m = S.mats + mrow;
             alive = false;
             if (mat_id < 0)
-                st.path_state[pid] = uint32_t(bounce) << 16;
+                finished = true, fin_state = uint32_t(bounce) << 16;
             else if (m[13] != R(0))
-                st.path_state[pid] = (uint32_t(bounce) << 16) | uint32_t(mat_id + 1);
+                finished = true, fin_state = (uint32_t(bounce) << 16) | uint32_t(mat_id + 1);
             else
                 shaded = true;
         }
@@ -855,7 +952,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 alive = true;
             }
             else
-                st.path_state[pid] = uint32_t(bounce + 1) << 16;
+                finished = true, fin_state = uint32_t(bounce + 1) << 16;
         }
 
         if constexpr (SQ1)
@@ -867,17 +964,34 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 const uint32_t e = (sq_head + sq_count + uint32_t(__popcll(pm & lt_mask))) % ShadowQueue<R>::CAP;
                 sq.xi[0][e] = park_x1, sq.xi[1][e] = park_x2;
                 sq.p2[0][e] = p.x, sq.p2[1][e] = p.y, sq.p2[2][e] = p.z;
-                sq.own[e] = hit_k;
-                sq.pid[e] = seg_pid, sq.bounce[e] = seg_bounce;
+                sq.own_bounce[e] = (uint32_t(hit_k) << 16) | seg_bounce;
+                sq.pid[e] = seg_pid;
             }
             sq_count += uint32_t(__popcll(pm));
+            sq_pushed += uint32_t(__popcll(pm));
             if (sq_count >= 64u)
                 drain(64u);
         }
+        // finished paths queue up for their resolve pass
+        {
+            const unsigned long long fm = __ballot(finished);
+            if (finished)
+            {
+                const uint32_t e = (dq_head + dq_count + uint32_t(__popcll(fm & lt_mask))) % DoneQueue::CAP;
+                dq.pid[e] = seg_pid, dq.state[e] = fin_state, dq.need[e] = sq_pushed;
+            }
+            dq_count += uint32_t(__popcll(fm));
+            if (dq_count >= 64u)
+            {
+                // resolve once the 64th path in line has no parked test left (or the ring fills up)
+                const uint32_t need64 = uint32_t(__builtin_amdgcn_readfirstlane(int(dq.need[(dq_head + 63u) % DoneQueue::CAP])));
+                if (int32_t(sq_drained - need64) >= 0 || dq_count > uint32_t(DoneQueue::CAP) - 64u)
+                    resolve(64u);
+            }
+        }
     }
-    if constexpr (SQ1)
-        while (sq_count > 0u)
-            drain(sq_count < 64u ? sq_count : 64u);
+    while (dq_count > 0u)
+        resolve(dq_count < 64u ? dq_count : 64u);
     // per-wave statistics (the wave owns its row)
     for (int off = 32; off > 0; off >>= 1)
     {
@@ -906,42 +1020,6 @@ template <bool BRUTE, bool TAB, bool SQ1>
 __global__ void __launch_bounds__(BLOCK, 4) k_trace_f32(DScene<float> S, DCamera cam, DBatch B, DState<float> st, int chunk)
 {
     trace_body<float, BRUTE, TAB, SQ1>(S, cam, B, st, chunk);
-}
-
-// one thread per path: folds the path's stack records back to front with the per-bounce max-clamp;
-// the per-sample result goes to result[.][pid]
-template <class R> __global__ void __launch_bounds__(BLOCK) k_resolve(DScene<R> S, DBatch B, DState<R> st)
-{
-    const int64_t pid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (pid >= B.n_paths)
-        return;
-    const int64_t N = st.N;
-    const uint32_t ps = st.path_state[pid];
-    const int len = int(ps >> 16), tm = int(ps & 0xffff);
-    R fr = R(0), fg = R(0), fb = R(0);
-    if (tm)
-    {
-        const R *m = S.mats + (size_t)(tm - 1) * MAT_STRIDE;
-        fr = m[0], fg = m[1], fb = m[2];
-    }
-    const R *rec = st.stack + (size_t)pid * B.depth * 6;
-    for (int i = len - 1; i >= 0; i--)
-    {
-        const R *q = rec + i * 6;
-        fr = q[0] + q[3] * fr;
-        fg = q[1] + q[4] * fg;
-        fb = q[2] + q[5] * fb;
-        R mx = fr;
-        if (fg > mx)
-            mx = fg;
-        if (fb > mx)
-            mx = fb;
-        if (R(0) > mx)
-            mx = R(0);
-        if (mx > R(1))
-            fr /= mx, fg /= mx, fb /= mx;
-    }
-    st.result[pid] = fr, st.result[N + pid] = fg, st.result[2 * N + pid] = fb;
 }
 
 // one thread per pixel of the batch: continues the running per-pixel sum in sample order

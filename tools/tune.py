@@ -22,6 +22,6 @@ for lb, reg, ppw in itertools.product(batches, regions, ppws):
     st = ctx.render_device(out.data_ptr(), mode=mode, spp=spp)
     sp = ctx.render_device(out.data_ptr(), mode=mode, spp=spp, profile=True)
     util = st["segments"] / (64.0 * max(st["wave_iterations"], 1))
-    print("batch 2^%d region %4d chunk %5d: %8.1f Mpaths/s  ms %.1f | profiled: trace %.1f resolve %.1f accumulate %.1f other %.1f | lane util %.3f" % (
-        lb, reg, ppw, st["paths"] / st["ms_total"] / 1e3, st["ms_total"], sp["ms_trace"], sp["ms_resolve"], sp["ms_accumulate"], sp["ms_other"], util), flush=True)
+    print("batch 2^%d region %4d chunk %5d: %8.1f Mpaths/s  ms %.1f | profiled: trace %.1f accumulate %.1f other %.1f | lane util %.3f" % (
+        lb, reg, ppw, st["paths"] / st["ms_total"] / 1e3, st["ms_total"], sp["ms_trace"], sp["ms_accumulate"], sp["ms_other"], util), flush=True)
     del ctx
