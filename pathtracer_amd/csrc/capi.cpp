@@ -295,8 +295,6 @@ int ptx_context_set_option(ptx_context *c, const char *name, int64_t value)
         c->ctx->default_batch_paths = value;
     else if (n == "shadow_queue" && (value == 0 || value == 1))
         c->ctx->shadow_queue = value != 0;
-    else if (n == "overlap_finish" && (value == 0 || value == 1))
-        c->ctx->overlap_finish = value != 0;
     else if (n == "trace_blocks_per_cu" && value >= 0 && value <= 64)
         c->ctx->trace_blocks_per_cu = static_cast<int>(value);
     else if (n == "chunk_paths" && value >= 64 && value <= (1 << 16))

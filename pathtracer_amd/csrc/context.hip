@@ -71,10 +71,8 @@ inline unsigned blocks_for(int64_t n) { return static_cast<unsigned>(std::max<in
 template <class R> struct Context::Impl
 {
     DeviceBuffer tri_pre, mats, lights, tri_nrm;
-    // two state buffers: while the tracer fills one, the other is resolved on the side stream
-    DeviceBuffer state_mem[2]; // each one slab carved into the DState arrays
-    DState<R> st[2];
-    DeviceBuffer totals;       // [8] statistics totals of a render call (shared by both buffers)
+    DeviceBuffer state_mem; // one slab carved into the DState arrays
+    DState<R> st;
     int64_t capacity = 0;
     int depth_cap = 0;
     bool ready = false;
@@ -207,7 +205,7 @@ template <class R> struct Context::Impl
         ready = true;
     }
 
-    // carve the state slabs for `n` paths of up to `depth` bounces
+    // carve the state slab for `n` paths of up to `depth` bounces
     void ensure_state(int64_t n, int depth)
     {
         if (n <= capacity && depth <= depth_cap)
@@ -225,25 +223,17 @@ template <class R> struct Context::Impl
         const size_t o_stack = take(N * 6 * sizeof(R) * depth);
         const size_t o_res = take(N * 3 * sizeof(R));
         const size_t o_ws = take(static_cast<size_t>(MAX_TRACE_WAVES) * 4 * sizeof(unsigned long long));
+        const size_t o_stats = take(sizeof(unsigned long long) * 8);
         const size_t o_pool = take(sizeof(unsigned int));
-        if (!totals.p)
-            totals.alloc(sizeof(unsigned long long) * 8);
-        for (int k = 0; k < 2; k++)
-        {
-            state_mem[k].release(); // both old slabs go before the new ones are taken
-        }
-        for (int k = 0; k < 2; k++)
-        {
-            state_mem[k].alloc(total);
-            char *base = static_cast<char *>(state_mem[k].p);
-            st[k].stack = reinterpret_cast<R *>(base + o_stack);
-            st[k].result = reinterpret_cast<R *>(base + o_res);
-            st[k].wave_stats = reinterpret_cast<unsigned long long *>(base + o_ws);
-            st[k].stats = static_cast<unsigned long long *>(totals.p);
-            st[k].pool = reinterpret_cast<unsigned int *>(base + o_pool);
-            st[k].N = n;
-            st[k].n_waves = 0;
-        }
+        state_mem.alloc(total);
+        char *base = static_cast<char *>(state_mem.p);
+        st.stack = reinterpret_cast<R *>(base + o_stack);
+        st.result = reinterpret_cast<R *>(base + o_res);
+        st.wave_stats = reinterpret_cast<unsigned long long *>(base + o_ws);
+        st.stats = reinterpret_cast<unsigned long long *>(base + o_stats);
+        st.pool = reinterpret_cast<unsigned int *>(base + o_pool);
+        st.N = n;
+        st.n_waves = 0;
         capacity = n;
         depth_cap = depth;
     }
@@ -277,38 +267,12 @@ Context::Context(int device) : device_(device)
 Context::~Context()
 {
     (void)hipSetDevice(device_);
-    if (side_stream_)
-    {
-        (void)hipStreamSynchronize(static_cast<hipStream_t>(side_stream_));
-        for (int k = 0; k < 2; k++)
-        {
-            (void)hipEventDestroy(traced_[k]);
-            (void)hipEventDestroy(finished_[k]);
-        }
-        (void)hipStreamDestroy(static_cast<hipStream_t>(side_stream_));
-    }
     delete f64_;
     delete f32_;
     delete geo_;
 }
 
 void Context::set_stream(void *s) { stream_ = s; }
-
-hipStream_t Context::side_stream()
-{
-    if (!side_stream_)
-    {
-        hipStream_t s2;
-        HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-        side_stream_ = s2;
-        for (int k = 0; k < 2; k++)
-        {
-            HIP_CHECK(hipEventCreateWithFlags(&traced_[k], hipEventDisableTiming));
-            HIP_CHECK(hipEventCreateWithFlags(&finished_[k], hipEventDisableTiming));
-        }
-    }
-    return static_cast<hipStream_t>(side_stream_);
-}
 
 void Context::build_accel(const Scene &sc)
 {
@@ -524,7 +488,6 @@ template <class R> struct TracePlan
 {
     void (*kernel)(DScene<R>, DCamera, DBatch, DState<R>, int) = nullptr;
     int blocks_per_cu = 1;
-    bool room_for_finish = false; // the finish kernels can be co-resident with a full tracer grid
 };
 
 template <class R, bool BRUTE> static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shadow_queue)
@@ -554,15 +517,6 @@ template <class R, bool BRUTE> static TracePlan<R> plan_trace(const DScene<R> &S
     if (per_cu <= 0)
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, p.kernel, BLOCK, 0));
     p.blocks_per_cu = std::max(per_cu, 1);
-    // vector registers left on a SIMD (512 per lane, allocated in blocks of 8) next to the
-    // tracer's waves: the memory-streaming finish kernels overlap with the tracer only if one of
-    // their waves still fits
-    hipFuncAttributes ft, fr;
-    HIP_CHECK(hipFuncGetAttributes(&ft, reinterpret_cast<const void *>(p.kernel)));
-    HIP_CHECK(hipFuncGetAttributes(&fr, reinterpret_cast<const void *>(k_accumulate<R>)));
-    auto granule = [](int regs) { return (std::max(regs, 1) + 7) / 8 * 8; };
-    const int waves_per_simd = p.blocks_per_cu * (BLOCK / 64) / 4;
-    p.room_for_finish = 512 - waves_per_simd * granule(ft.numRegs) >= granule(fr.numRegs);
     return p;
 }
 
@@ -676,21 +630,14 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
         throw std::runtime_error("arg: batch_paths must stay below 2^31");
     const int chunk = std::max(64, chunk_paths);
     im.ensure_state(cap, depth);
-    HIP_CHECK(hipMemsetAsync(im.totals.p, 0, sizeof(unsigned long long) * 8, s));
-    for (int k = 0; k < 2; k++)
-        HIP_CHECK(hipMemsetAsync(im.st[k].pool, 0, sizeof(unsigned int), s));
+    HIP_CHECK(hipMemsetAsync(im.st.stats, 0, sizeof(unsigned long long) * 8, s));
+    HIP_CHECK(hipMemsetAsync(im.st.pool, 0, sizeof(unsigned int), s));
 
     auto S = make_dscene<R>(sc, *geo_, im.tri_pre.p, im.mats.p, im.lights.p, im.tri_nrm.p, brute_);
     DCamera cam = make_camera(sc);
     RenderTimers *tm = o.profile ? &timers_ : nullptr;
-    // The tracer is bound by vector-ALU issue and leaves the memory system idle; resolve and
-    // accumulate are pure memory streaming.  Batch i is therefore finished on a side stream while
-    // the tracer already works on batch i + 1 in the other state buffer.  (Profiling mode keeps
-    // everything on one stream so that the per-kernel times add up.)
     // The grid of the tracer is just large enough to fill the device: its waves are persistent.
     const TracePlan<R> plan = brute_ ? plan_trace<R, true>(S, trace_blocks_per_cu, shadow_queue) : plan_trace<R, false>(S, trace_blocks_per_cu, shadow_queue);
-    const bool overlap = !o.profile && overlap_finish && plan.room_for_finish;
-    hipStream_t s2 = overlap ? side_stream() : s;
 
     hipEvent_t ev0, ev1;
     HIP_CHECK(hipEventCreate(&ev0));
@@ -713,29 +660,16 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
             B.seed = o.seed;
             B.n_pix = static_cast<int64_t>(nr) * n_cols;
             B.n_paths = B.n_pix * B.n_samples;
-            const int k = static_cast<int>(passes & 1);
-            if (overlap && passes >= 2)
-                HIP_CHECK(hipStreamWaitEvent(s, finished_[k], 0)); // buffer k is free again
             if (tm)
                 tm->mark(s, RenderTimers::TRACE);
-            launch_trace<R>(plan, S, cam, B, im.st[k], s, chunk, n_cus_);
-            if (overlap)
-            {
-                HIP_CHECK(hipEventRecord(traced_[k], s));
-                HIP_CHECK(hipStreamWaitEvent(s2, traced_[k], 0));
-            }
-            launch_finish<R>(S, B, im.st[k], d_sum, s2, tm);
-            if (overlap)
-                HIP_CHECK(hipEventRecord(finished_[k], s2));
+            launch_trace<R>(plan, S, cam, B, im.st, s, chunk, n_cus_);
+            launch_finish<R>(S, B, im.st, d_sum, s, tm);
             passes++;
         }
     }
-    if (overlap)
-        for (int k = 0; k < 2 && k < static_cast<int>(passes); k++)
-            HIP_CHECK(hipStreamWaitEvent(s, finished_[k], 0)); // the caller's stream sees the finished sums
     HIP_CHECK(hipEventRecord(ev1, s));
     unsigned long long h_stats[8] = {0};
-    HIP_CHECK(hipMemcpyAsync(h_stats, im.totals.p, sizeof(h_stats), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(h_stats, im.st.stats, sizeof(h_stats), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     float ms = 0;
     HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));

@@ -74,13 +74,11 @@ public:
 
     // scenes up to this many triangles are intersected by the all-triangles loop
     int brute_force_limit = 64;
-    int64_t default_batch_paths = int64_t(1) << 24;
+    int64_t default_batch_paths = int64_t(1) << 26;
     // path ids a wave of the tracer takes from the pool at a time (>= 64)
-    int chunk_paths = 256;
+    int chunk_paths = 64;
     // workgroups of the tracer per compute unit (<= 0: what the occupancy calculator reports)
     int trace_blocks_per_cu = 0;
-    // resolve / accumulate of batch i on a side stream while the tracer runs batch i + 1
-    bool overlap_finish = true;
     // single-square-light scenes: park visibility tests in a per-wave LDS queue (full-wave tests)
     bool shadow_queue = true;
 
@@ -89,14 +87,11 @@ public:
 
 private:
     void require_scene() const;
-    hipStream_t side_stream();
     template <class R> void render_impl(Impl<R> &im, const RenderOpts &o, double *d_sum, RenderStats &stats);
 
     int device_;
     int n_cus_ = 1;
     void *stream_ = nullptr;
-    void *side_stream_ = nullptr;
-    hipEvent_t traced_[2] = {nullptr, nullptr}, finished_[2] = {nullptr, nullptr};
     Scene scene_;
     Bvh bvh_;
     bool brute_ = true, have_scene_ = false;
