@@ -112,6 +112,13 @@ int ptx_scene_copy_vertex_ids(const ptx_scene *, int32_t *vertex_ids);
 int ptx_scene_copy_tables(const ptx_scene *, double *mats12, double *lights16);
 int ptx_scene_copy_camera(const ptx_scene *, double *view16, double *cam_pos3, double *raster2world16);
 const char *ptx_scene_result_path(const ptx_scene *);
+/* Acceleration data of the all-triangles intersector, for inspection and tests (no counterpart in
+ * the reference): number of plane records and of coplanar triangle pairs among them, the
+ * candidate-bit -> triangle table [64] (-1: none), and per record the set of records (bit mask)
+ * that can block a segment between it and the light -- all ones unless the scene has exactly one
+ * light and it is a square light.  Null outputs are skipped. */
+int ptx_scene_plane_records(const ptx_scene *, int32_t *n_records, int32_t *n_pairs,
+                            int32_t *rec_tri64, uint32_t *blockers32);
 
 /* ---- context / accel -------------------------------------------------------------------------
  * ptx_context_create + ptx_build_accel replace cPathTracer::Init (src/tracing/cPathTracer.cpp:20-57)

@@ -105,6 +105,14 @@ class Scene:
     def result_path(self):
         return _lib.lib().ptx_scene_result_path(self._h).decode()
 
+    def plane_records(self):
+        """Plane records of the all-triangles intersector: (n_records, n_pairs, rec_tri[64], blockers[32])."""
+        n = np.zeros(2, dtype=np.int32)
+        rec_tri = np.zeros(64, dtype=np.int32)
+        blockers = np.zeros(32, dtype=np.uint32)
+        check(_lib.lib().ptx_scene_plane_records(self._h, _ptr(n[0:1]), _ptr(n[1:2]), _ptr(rec_tri), _ptr(blockers)))
+        return int(n[0]), int(n[1]), rec_tri, blockers
+
 
 class Context:
     """One GPU: device copy of a scene plus wavefront state."""
@@ -142,6 +150,10 @@ class Context:
         self._scene = scene
         i = scene.info
         self.width, self.height = i.width, i.height
+
+    def set_option(self, name, value):
+        """Tunables of ptx_context_set_option (set before build_accel)."""
+        check(_lib.lib().ptx_context_set_option(self._h, name.encode(), int(value)))
 
     def accel_info(self):
         a = np.zeros(5, dtype=np.int32)

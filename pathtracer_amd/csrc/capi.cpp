@@ -1,6 +1,7 @@
 // extern "C" boundary of libptx_amd.so: translates exceptions into status codes, owns the handles.
 #include "../../include/ptx.h"
 #include "context.hpp"
+#include "plane_records.hpp"
 #include "scene.hpp"
 
 #include <cstring>
@@ -255,6 +256,36 @@ int ptx_scene_copy_camera(const ptx_scene *s, double *view16, double *cam_pos3, 
 }
 
 const char *ptx_scene_result_path(const ptx_scene *s) { return s ? s->sc.result_path.c_str() : ""; }
+
+int ptx_scene_plane_records(const ptx_scene *s, int32_t *n_records, int32_t *n_pairs, int32_t *rec_tri64, uint32_t *blockers32)
+{
+    if (!s)
+        return fail_arg("ptx_scene_plane_records: null scene");
+    PTX_TRY
+    ptx::PlaneRecords pr;
+    ptx::build_plane_records(s->sc.verts.data(), s->sc.n_tris(), pr);
+    if (n_records)
+        *n_records = pr.n_recs;
+    if (n_pairs)
+        *n_pairs = pr.n_pairs;
+    if (rec_tri64)
+        for (int k = 0; k < 64; k++)
+            rec_tri64[k] = pr.rec_tri[k];
+    if (blockers32)
+    {
+        std::vector<uint32_t> blk(32, 0xFFFFFFFFu);
+        if (pr.n_recs <= 32 && s->sc.lights.size() == 1 && s->sc.lights[0].type == 0)
+        {
+            double corners[4][3];
+            ptx::square_light_corners(s->sc.lights[0], corners);
+            blk = ptx::blocker_masks(s->sc.verts.data(), pr, corners);
+        }
+        for (int k = 0; k < 32; k++)
+            blockers32[k] = blk[k];
+    }
+    return PTX_OK;
+    PTX_CATCH
+}
 
 int ptx_context_create(int32_t hip_device, ptx_context **out)
 {

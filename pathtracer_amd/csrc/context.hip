@@ -325,14 +325,8 @@ void Context::build_accel(const Scene &sc)
         std::vector<uint32_t> blk(32, 0xFFFFFFFFu);
         if (brute_ && sc.lights.size() == 1 && sc.lights[0].type == 0)
         {
-            const Light &L = sc.lights[0];
             double corners[4][3];
-            for (int c3 = 0; c3 < 3; c3++)
-            {
-                const double e10 = L.p[1][c3] - L.p[0][c3], e21 = L.p[2][c3] - L.p[1][c3];
-                corners[0][c3] = L.p[0][c3], corners[1][c3] = L.p[0][c3] + e10;
-                corners[2][c3] = L.p[0][c3] + e10 + e21, corners[3][c3] = L.p[0][c3] + e21;
-            }
+            square_light_corners(sc.lights[0], corners);
             blk = blocker_masks(sc.verts.data(), pr, corners);
         }
         upload(geo_->rec_block, blk, s);

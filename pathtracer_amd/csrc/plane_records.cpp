@@ -304,4 +304,14 @@ std::vector<uint32_t> blocker_masks(const float *verts, const PlaneRecords &pr, 
     return masks;
 }
 
+void square_light_corners(const Light &L, double corners[4][3])
+{
+    for (int c3 = 0; c3 < 3; c3++)
+    {
+        const double e10 = L.p[1][c3] - L.p[0][c3], e21 = L.p[2][c3] - L.p[1][c3];
+        corners[0][c3] = L.p[0][c3], corners[1][c3] = L.p[0][c3] + e10;
+        corners[2][c3] = L.p[0][c3] + e10 + e21, corners[3][c3] = L.p[0][c3] + e21;
+    }
+}
+
 } // namespace ptx

@@ -2,6 +2,8 @@
 // exactly coplanar triangles that share an edge (the two halves of a quad face).  See kernels.hpp
 // for the record layout and the device-side test.
 #pragma once
+#include "scene.hpp"
+
 #include <cstdint>
 #include <vector>
 
@@ -29,5 +31,8 @@ void build_plane_records(const float *verts, int n_tris, PlaneRecords &out);
 // all of the light in one closed half space, at least one of the two well clear of the plane: a
 // segment between them then never crosses the plane in its interior.
 std::vector<uint32_t> blocker_masks(const float *verts, const PlaneRecords &pr, const double light[4][3]);
+
+// corners of the parallelogram a square light is sampled on: P0 + x1 (P1 - P0) + x2 (P2 - P1)
+void square_light_corners(const Light &L, double corners[4][3]);
 
 } // namespace ptx

@@ -209,6 +209,29 @@ def test_batching_sharding_and_bands_are_bit_invariant(cbox64):
         assert (parts[k][(rows // 4) % 3 != k] == 0).all()
 
 
+def test_tracer_scheduling_options_are_bit_invariant(root):
+    """How paths are handed to lanes (pool chunk, grid size), whether visibility tests are parked
+    in the LDS queue or run in place, and which intersector runs must not change a single bit: a
+    path's result depends on its (pixel, sample) only."""
+    s, ref = load(root, "config/cbox.conf", width=96, height=96, spp=6)
+    base, st = make_ctx(s).render(mode="f64")
+    for opts in (dict(chunk_paths=4096), dict(trace_blocks_per_cu=1), dict(shadow_queue=0),
+                 dict(shadow_queue=0, brute_force_limit=0), dict(chunk_paths=64, trace_blocks_per_cu=3)):
+        c = pt.Context(0, brute_force_limit=opts.pop("brute_force_limit", None))
+        for k, v in opts.items():
+            c.set_option(k, v)
+        c.build_accel(s)
+        img, st2 = c.render(mode="f64")
+        assert np.array_equal(img, base), opts
+        assert (st2["segments"], st2["shadow_rays"], st2["records"]) == (st["segments"], st["shadow_rays"], st["records"])
+    # f32: same statement
+    b32, _ = make_ctx(s).render(mode="f32")
+    c = pt.Context(0)
+    c.set_option("shadow_queue", 0)
+    c.build_accel(s)
+    assert np.array_equal(c.render(mode="f32")[0], b32)
+
+
 def test_render_f32_meets_rmse_bar(root):
     s, ref = load(root, "config/cbox.conf", width=64, height=64, spp=16)
     c = make_ctx(s)
