@@ -129,8 +129,11 @@ int ptx_context_set_stream(ptx_context *, void *hip_stream);
 void ptx_context_destroy(ptx_context *);
 /* Tunables: "brute_force_limit" (scenes with at most this many triangles use the all-triangles
  * intersector instead of the BVH; default and maximum 64), "default_batch_paths" (paths per
- * tracer launch), "chunk_paths" (path ids a wave of the tracer takes from the pool at a time, 64..65536).
- * Set before ptx_build_accel. */
+ * tracer launch; default 2^26), "chunk_paths" (path ids a wave of the tracer takes from the pool at
+ * a time, 64..65536), "trace_blocks_per_cu" (workgroups of the tracer per compute unit; 0 = what
+ * the occupancy calculator reports), "shadow_queue" (1/0: park the visibility tests of
+ * one-square-light scenes in the per-wave LDS queue, or run them in place).  Results do not depend
+ * on any of them.  Set before ptx_build_accel. */
 int ptx_context_set_option(ptx_context *, const char *name, int64_t value);
 int ptx_build_accel(ptx_context *, const ptx_scene *);
 /* BVH statistics of the last build: n_nodes, n_leaves, max_depth, max_leaf_tris, brute_force flag */
