@@ -1,0 +1,136 @@
+"""GPU edge cases through the C ABI, against the oracle: table sizes beyond the LDS copies (many
+materials, many lights), empty and degenerate geometry, no lights, extreme depths, and the hand-over
+between the all-triangles intersector and the BVH at 64 / 65 triangles."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+import pathtracer_amd as pt
+from oracle import oracle, scene_io
+from test_gpu_parity import assert_f64_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_scene(ref):
+    return pt.Scene.from_arrays(ref.verts.astype(np.float32), ref.normals.astype(np.float32), ref.mat_ids, ref.mats, ref.lights,
+                                ref.view, ref.cam_pos, ref.fov_deg, ref.near, ref.width, ref.height, ref.depth, ref.spp,
+                                ref.enable_indirect, ref.enable_bary_normal)
+
+
+def render_both(ref, **ctx_kw):
+    c = pt.Context(0, **ctx_kw)
+    c.build_accel(gpu_scene(ref))
+    img, st = c.render(mode="f64", seed=13)
+    oimg, ost = oracle.Oracle(ref, seed=13).render(stats=True)
+    return img, st, oimg, ost, c
+
+
+@pytest.fixture()
+def cbox(root):
+    return scene_io.load_conf(os.path.join(root, "config/cbox.conf"), root_dir=root, width=40, height=40, spp=4)
+
+
+def test_more_materials_than_the_lds_table_holds(cbox):
+    ref = copy.deepcopy(cbox)
+    n = ref.verts.shape[0]
+    # one material per triangle, plus padding to 40 entries: same colours, so the image is unchanged
+    mats = np.concatenate([ref.mats[ref.mat_ids], np.tile(ref.mats[:1], (40 - n, 1))])
+    base, _, _, _, _ = render_both(cbox)
+    ref.mats, ref.mat_ids = mats, np.arange(n, dtype=np.int32)
+    img, st, oimg, ost, _ = render_both(ref)
+    assert_f64_parity(img, oimg, st, ost)
+    assert np.array_equal(img, base)                      # tables from global memory: same bits as from LDS
+
+
+def test_more_lights_than_the_lds_table_holds(cbox):
+    ref = copy.deepcopy(cbox)
+    rng = np.random.default_rng(3)
+    lights = [ref.lights[0]]
+    for k in range(34):                                   # 35 lights: squares and spheres mixed
+        L = np.zeros(16)
+        if k % 2:
+            L[0] = 1.0                                    # sphere: centre + radius
+            L[1:4] = rng.uniform(0.2, 1.0, 3)
+            L[4:7] = rng.uniform(1.0, 4.5, 3)
+            L[7] = rng.uniform(0.05, 0.3)
+        else:
+            L[0] = 0.0                                    # small square under the ceiling
+            L[1:4] = rng.uniform(0.5, 3.0, 3)
+            x, z = rng.uniform(0.5, 4.5, 2)
+            L[4:16] = np.array([[x, 5.4, z], [x + 0.3, 5.4, z], [x + 0.3, 5.4, z + 0.3], [x, 5.4, z + 0.3]]).ravel()
+        lights.append(L)
+    ref.lights = np.array(lights)
+    ref.depth = 4
+    img, st, oimg, ost, _ = render_both(ref)
+    assert_f64_parity(img, oimg, st, ost, depth=4)
+    assert st["shadow_rays"] > 0
+
+
+def test_no_lights_and_no_triangles(cbox):
+    ref = copy.deepcopy(cbox)
+    ref.lights = np.zeros((0, 16))
+    img, st, oimg, ost, _ = render_both(ref)
+    assert_f64_parity(img, oimg, st, ost)
+    assert st["shadow_rays"] == 0
+    empty = copy.deepcopy(cbox)
+    empty.verts, empty.normals = np.zeros((0, 3, 3)), np.zeros((0, 3, 3))
+    empty.mat_ids = np.zeros(0, dtype=np.int32)
+    img, st, oimg, ost, _ = render_both(empty)
+    assert (img == 0).all() and (oimg == 0).all()
+    assert st["paths"] == 40 * 40 * 4 and st["segments"] == st["paths"] and st["records"] == 0
+
+
+def test_degenerate_and_duplicate_triangles(cbox):
+    ref = copy.deepcopy(cbox)
+    v = ref.verts.copy()
+    extra = np.stack([np.stack([v[6][0], v[6][0], v[6][1]]),          # zero area: two equal corners
+                      np.stack([v[6][0], v[6][0], v[6][0]]),          # a point
+                      v[7]])                                          # exact duplicate of face 7 (tie -> lowest id)
+    ref.verts = np.concatenate([v, extra])
+    ref.normals = np.concatenate([ref.normals, ref.normals[[6, 6, 7]]])
+    ref.mat_ids = np.concatenate([ref.mat_ids, ref.mat_ids[[6, 6, 7]]]).astype(np.int32)
+    img, st, oimg, ost, c = render_both(ref)
+    assert_f64_parity(img, oimg, st, ost)
+    assert np.array_equal(c.first_hit(), oracle.Oracle(ref).first_hit())
+
+
+@pytest.mark.parametrize("depth", [1, 2, 40])
+def test_extreme_depths(cbox, depth):
+    ref = copy.deepcopy(cbox)
+    ref.depth = depth
+    img, st, oimg, ost, _ = render_both(ref)
+    assert_f64_parity(img, oimg, st, ost, depth=depth)
+
+
+def test_intersector_hand_over_at_the_record_limit(cbox):
+    """The all-triangles intersector takes scenes of up to 64 triangles in up to 32 plane records:
+    the Cornell box (14 records) plus 18 quads still uses it, plus 19 quads goes to the BVH; both
+    agree with the oracle."""
+    for quads in (18, 19):
+        ref = copy.deepcopy(cbox)
+        rng = np.random.default_rng(quads)
+        c0 = rng.uniform(1.0, 4.5, (quads, 3))
+        e1 = rng.uniform(-0.3, 0.3, (quads, 3))
+        e2 = np.cross(e1, rng.uniform(-1, 1, (quads, 3)))
+        e2 *= 0.3 / np.linalg.norm(e2, axis=1, keepdims=True)
+        # axis-parallel rectangles in float so that the four corners are exactly coplanar
+        e1[:, 1:] = 0.0
+        e2[:, 0] = 0.0
+        f = lambda x: x.astype(np.float32).astype(np.float64)
+        p0, p1, p3 = f(c0), f(f(c0) + f(e1)), f(f(c0) + f(e2))
+        p2 = f(p1 + (p3 - p0))
+        tris = np.stack([np.stack([p0, p1, p2], 1), np.stack([p0, p2, p3], 1)], 1).reshape(-1, 3, 3)
+        nrm = np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0])
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        ref.verts = np.concatenate([ref.verts, tris])
+        ref.normals = np.concatenate([ref.normals, f(np.repeat(nrm[:, None, :], 3, axis=1))])
+        ref.mat_ids = np.concatenate([ref.mat_ids, np.repeat(rng.integers(0, len(ref.mats), quads), 2)]).astype(np.int32)
+        img, st, oimg, ost, c = render_both(ref)
+        n_recs, n_pairs, _, _ = gpu_scene(ref).plane_records()
+        assert c.accel_info()["brute_force"] == (n_recs <= 32)
+        assert (quads == 18) == (n_recs <= 32)
+        assert_f64_parity(img, oimg, st, ost)
+        assert np.array_equal(c.first_hit(), oracle.Oracle(ref).first_hit())
