@@ -4,7 +4,7 @@
 One "step" = one full pass of the hot path over the workload: camera rays, up to 15 bounces of
 closest hit / shading / NEE with visibility per path, resolve, accumulate -- i.e.
 cPathTracer::Process of the reference for
-config/cbox.conf at 1024 x 1024 x 256 spp (BASELINE.json configs[1]).  With N GPUs every rank
+config/cbox.conf at 1024 x 1024 x 256 spp (the configuration the headline metric is quoted on).  With N GPUs every rank
 renders its own range of 256 samples of the same image (weak scaling: 256 * N spp in total) and the
 per-pixel sums are reduced onto rank 0 over RCCL inside the timed region.
 
@@ -208,7 +208,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.mode, "data": "synthetic",
             "config": {"workload": "cbox %dx%d, %d spp per GPU, depth %d, 26 triangles, 1 square light "
-                                   "(config/cbox.conf, BASELINE configs[1])" % (W, H, args.spp, info.depth),
+                                   "(config/cbox.conf, the headline configuration)" % (W, H, args.spp, info.depth),
                        "global_spp": spp_total, "paths_per_step": paths_per_step,
                        "sharding": "sample ranges per rank + RCCL reduce(sum) of the radiance sums to rank 0"},
             "mrays_per_s": round((st["segments"] + st["shadow_rays"]) * world * args.steps / dt / 1e6, 1),

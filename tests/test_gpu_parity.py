@@ -249,7 +249,7 @@ def test_render_f32_meets_rmse_bar(root):
 
 
 def test_full_size_properties(root):
-    """BASELINE size (1024 x 1024): properties that need no CPU render."""
+    """Headline size (1024 x 1024): properties that need no CPU render."""
     s, ref = load(root, "config/cbox.conf", width=1024, height=1024, spp=4)
     c = make_ctx(s)
     a, sa = c.render(mode="f64", spp=4)
