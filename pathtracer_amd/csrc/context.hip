@@ -488,25 +488,29 @@ template <class R, bool BRUTE> static TracePlan<R> plan_trace(const DScene<R> &S
 {
     TracePlan<R> p;
     const bool tab = S.n_mats <= LDS_MATS && S.n_lights <= LDS_LIGHTS;
-    // one light, and it is a square light: visibility tests go through the per-wave LDS queue
-    // (all-triangles intersector only: the BVH variant needs its LDS for the traversal stacks)
-    const bool sq1 = BRUTE && S.n_lights == 1 && S.n_square == 1 && shadow_queue;
-    if constexpr (sizeof(R) == 8)
-    {
-        if constexpr (BRUTE)
-            p.kernel = tab ? (sq1 ? k_trace_f64<true, true, true> : k_trace_f64<true, true, false>)
-                           : (sq1 ? k_trace_f64<true, false, true> : k_trace_f64<true, false, false>);
+    // how visibility tests are compiled (see trace_body): none / parked in the LDS queue / in place
+    const int lights = S.n_square == 0 ? 0 : ((BRUTE && S.n_lights == 1 && shadow_queue) ? 1 : 2);
+    auto pick = [&](auto tab_c) {
+        constexpr bool TAB = decltype(tab_c)::value;
+        if constexpr (sizeof(R) == 8)
+        {
+            if constexpr (BRUTE)
+                p.kernel = lights == 1 ? k_trace_f64<true, TAB, 1> : k_trace_f64<true, TAB, 2>;
+            else
+                p.kernel = lights == 0 ? k_trace_f64<false, TAB, 0> : k_trace_f64<false, TAB, 2>;
+        }
         else
-            p.kernel = tab ? k_trace_f64<false, true, false> : k_trace_f64<false, false, false>;
-    }
+        {
+            if constexpr (BRUTE)
+                p.kernel = lights == 1 ? k_trace_f32<true, TAB, 1> : k_trace_f32<true, TAB, 2>;
+            else
+                p.kernel = lights == 0 ? k_trace_f32<false, TAB, 0> : k_trace_f32<false, TAB, 2>;
+        }
+    };
+    if (tab)
+        pick(std::true_type());
     else
-    {
-        if constexpr (BRUTE)
-            p.kernel = tab ? (sq1 ? k_trace_f32<true, true, true> : k_trace_f32<true, true, false>)
-                           : (sq1 ? k_trace_f32<true, false, true> : k_trace_f32<true, false, false>);
-        else
-            p.kernel = tab ? k_trace_f32<false, true, false> : k_trace_f32<false, false, false>;
-    }
+        pick(std::false_type());
     int per_cu = blocks_per_cu;
     if (per_cu <= 0)
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, p.kernel, BLOCK, 0));

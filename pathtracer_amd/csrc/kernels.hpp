@@ -250,6 +250,83 @@ __device__ __forceinline__ unsigned long long drop_own_plane(unsigned long long 
     return mask;
 }
 
+// State of one BVH closest-hit traversal, so that it can be advanced one node at a time.
+template <class R> struct Trav
+{
+    int node, sp, target, best_face;
+    R best;
+    V3<R> pt, inv;
+};
+template <class R> __device__ __forceinline__ void trav_init(Trav<R> &T, V3<R> d)
+{
+    T.node = 0, T.sp = 0, T.target = -1, T.best_face = 0x7fffffff;
+    T.best = Consts<R>::big;
+    T.pt = {R(0), R(0), R(0)};
+    T.inv = {R(1) / d.x, R(1) / d.y, R(1) / d.z};
+}
+// One node visit: slab tests of both children, exact tests of leaf triangles (winner = smallest
+// distance beyond self_eps, ties -> lowest face id), then near-first descent with the far child on
+// the lane's LDS stack stk[level * BLOCK].  Returns false once the traversal is complete.
+template <class R> __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, Trav<R> &T, int *stk)
+{
+    const R self_eps = Consts<R>::self_eps;
+    const int lane_stride = BLOCK;
+    const BvhNode nd = S.nodes[T.node];
+    R tmax = T.best * (R(1) + (sizeof(R) == 8 ? R(1e-9) : R(1e-4))) + R(1e-9);
+    R e0 = box_entry(nd.lo0, nd.hi0, o, T.inv, R(-1e-6), tmax);
+    R e1 = box_entry(nd.lo1, nd.hi1, o, T.inv, R(-1e-6), tmax);
+    int c0 = nd.c0, c1 = nd.c1;
+    bool h0 = e0 > R(-1.5), h1 = e1 > R(-1.5);
+#pragma unroll
+    for (int side = 0; side < 2; side++)
+    {
+        int c = side == 0 ? c0 : c1;
+        bool h = side == 0 ? h0 : h1;
+        if (h && c < 0)
+        {
+            int enc = ~c, first = enc >> 3, cnt = (enc & 7) + 1;
+            for (int k = first; k < first + cnt; k++)
+            {
+                R t;
+                if (tri_test(S.tri_pre + (size_t)k * 12, o, d, t))
+                {
+                    V3<R> p = o + t * d;
+                    R dist = norm(p - o);
+                    int face = S.tri_face[k];
+                    if (dist > self_eps && (dist < T.best || (dist == T.best && face < T.best_face)))
+                    {
+                        T.best = dist;
+                        T.best_face = face;
+                        T.target = k;
+                        T.pt = p;
+                    }
+                }
+            }
+        }
+    }
+    bool i0 = h0 && c0 >= 0, i1 = h1 && c1 >= 0;
+    if (i0 && i1)
+    {
+        int near = e0 <= e1 ? c0 : c1, far = e0 <= e1 ? c1 : c0;
+        if (T.sp < BVH_STACK)
+            stk[T.sp * lane_stride] = far;
+        T.sp++;
+        T.node = near;
+    }
+    else if (i0)
+        T.node = c0;
+    else if (i1)
+        T.node = c1;
+    else
+    {
+        if (T.sp == 0)
+            return false;
+        T.sp--;
+        T.node = stk[T.sp * lane_stride];
+    }
+    return true;
+}
+
 // closest hit.  Returns the intersector-order triangle index (or -1) and the hit point.
 // Winner = smallest |p - o| among accepted hits with |p - o| > self_eps; ties -> lowest face id.
 template <class R, bool BRUTE>
@@ -322,69 +399,13 @@ __device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d,
         }
         return target;
     }
-    int best_face = 0x7fffffff;
-    V3<R> inv = {R(1) / d.x, R(1) / d.y, R(1) / d.z};
-    int sp = 0;
-    int node = 0;
-    const int lane_stride = BLOCK;
-    for (;;)
+    Trav<R> T;
+    trav_init(T, d);
+    while (bvh_step(S, o, d, T, stk))
     {
-        const BvhNode nd = S.nodes[node];
-        R tmax = best * (R(1) + (sizeof(R) == 8 ? R(1e-9) : R(1e-4))) + R(1e-9);
-        R e0 = box_entry(nd.lo0, nd.hi0, o, inv, R(-1e-6), tmax);
-        R e1 = box_entry(nd.lo1, nd.hi1, o, inv, R(-1e-6), tmax);
-        int c0 = nd.c0, c1 = nd.c1;
-        bool h0 = e0 > R(-1.5), h1 = e1 > R(-1.5);
-        // leaves are tested right away; internal children are visited near-first
-#pragma unroll
-        for (int side = 0; side < 2; side++)
-        {
-            int c = side == 0 ? c0 : c1;
-            bool h = side == 0 ? h0 : h1;
-            if (h && c < 0)
-            {
-                int enc = ~c, first = enc >> 3, cnt = (enc & 7) + 1;
-                for (int k = first; k < first + cnt; k++)
-                {
-                    R t;
-                    if (tri_test(S.tri_pre + (size_t)k * 12, o, d, t))
-                    {
-                        V3<R> p = o + t * d;
-                        R dist = norm(p - o);
-                        int face = S.tri_face[k];
-                        if (dist > self_eps && (dist < best || (dist == best && face < best_face)))
-                        {
-                            best = dist;
-                            best_face = face;
-                            target = k;
-                            pt = p;
-                        }
-                    }
-                }
-            }
-        }
-        bool i0 = h0 && c0 >= 0, i1 = h1 && c1 >= 0;
-        if (i0 && i1)
-        {
-            int near = e0 <= e1 ? c0 : c1, far = e0 <= e1 ? c1 : c0;
-            if (sp < BVH_STACK)
-                stk[sp * lane_stride] = far;
-            sp++;
-            node = near;
-        }
-        else if (i0)
-            node = c0;
-        else if (i1)
-            node = c1;
-        else
-        {
-            if (sp == 0)
-                break;
-            sp--;
-            node = stk[sp * lane_stride];
-        }
     }
-    return target;
+    pt = T.pt;
+    return T.target;
 }
 
 // segment visibility p1 -> p2: blocked iff some triangle has self_eps < t < |p1 - p2| - self_eps
@@ -596,12 +617,21 @@ struct DoneQueue
     uint32_t pid[CAP], state[CAP], need[CAP];
 };
 
-// SQ1: the scene has exactly one light and it is a square light -- every bounce has at most one
-// visibility test, which goes through the wave's ShadowQueue.  Otherwise the tests run in place.
-template <class R, bool BRUTE, bool TAB, bool SQ1>
+// LIGHTS selects how visibility tests are compiled: 0 -- the scene has no square light, there are
+// none; 1 -- exactly one light and it is a square light: every bounce has at most one test, which
+// goes through the wave's ShadowQueue (all-triangles intersector only); 2 -- tests run in place.
+//
+// With the BVH the closest-hit search is a per-lane loop of very uneven length (on the 336 k
+// triangle room: 16 node visits on average, 91 for the slowest lane of a wave), so it is not run to
+// completion inside one bounce iteration.  Every lane keeps a resumable traversal; the wave advances
+// all unfinished traversals one node at a time and only turns to shading -- and to starting new
+// paths -- when enough lanes are waiting for it.  Lanes with a long traversal simply keep going
+// while the others shade, start their next ray and catch up.
+template <class R, bool BRUTE, bool TAB, int LIGHTS>
 __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &cam, const DBatch &B, const DState<R> &st, int chunk)
 {
     constexpr bool NRM = BRUTE; // all-triangles intersector = at most 64 triangles: the per-triangle tables fit LDS
+    constexpr bool SQ1 = LIGHTS == 1;
     __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : BVH_STACK * BLOCK];
     __shared__ R lds_mats[TAB ? LDS_MATS * MAT_STRIDE : 1];
     __shared__ R lds_lights[TAB ? (SQ1 ? 1 : LDS_LIGHTS) * LIGHT_STRIDE : 1];
@@ -647,6 +677,9 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
     uint32_t dq_head = 0, dq_count = 0; // wave-uniform
 
     bool alive = false;
+    bool trav_done = false; // BVH: the lane's closest-hit traversal is complete (its path waits for shading)
+    Trav<R> T;
+    trav_init(T, V3<R>{R(1), R(1), R(1)});
     V3<R> o = {R(0), R(0), R(0)}, d = {R(0), R(0), R(0)};
     uint32_t pid = 0, sample = 0;
     int bounce = 0, prim = -1;
@@ -782,6 +815,22 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
 
     for (;;)
     {
+        if constexpr (!BRUTE)
+        {
+            // ---- advance the unfinished traversals until enough lanes wait for shading / a new path --
+            for (;;)
+            {
+                const int n_trav = __popcll(__ballot(alive && !trav_done));
+                if (n_trav == 0)
+                    break;
+                const bool can_start = !(blk_pos == blk_cnt && next == end && drained);
+                const int n_serve = __popcll(__ballot(alive && trav_done)) + (can_start ? __popcll(__ballot(!alive)) : 0);
+                if (n_serve >= 32 || (n_serve > 0 && n_trav <= n_serve))
+                    break;
+                if (alive && !trav_done)
+                    trav_done = !bvh_step(S, o, d, T, stk);
+            }
+        }
         // ---- idle lanes start the next paths ------------------------------------------------------
         const unsigned long long idle = __ballot(!alive);
         if (idle != 0ull && blk_pos == blk_cnt && !(next == end && drained))
@@ -827,6 +876,8 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 sample = uint32_t(B.sample0) + pid / n_pix;
                 bounce = 0, prim = -1;
                 alive = true;
+                if constexpr (!BRUTE)
+                    trav_init(T, d), trav_done = false;
             }
         }
         {
@@ -843,10 +894,13 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         V3<R> p = {R(0), R(0), R(0)};
         int hit_k = -1;
         const R *m = nullptr; // the address space (LDS or global) is fixed at compile time
-        if (alive)
+        if (BRUTE ? alive : (alive && trav_done))
         {
             n_seg++;
-            hit_k = closest_hit<R, BRUTE>(S, o, d, p, stk, prim);
+            if constexpr (BRUTE)
+                hit_k = closest_hit<R, BRUTE>(S, o, d, p, stk, prim);
+            else
+                hit_k = T.target, p = T.pt;
             int mat_id = -1;
             if (hit_k >= 0)
                 mat_id = NRM ? lds_tmat[hit_k] : S.tri_mat[hit_k];
@@ -934,8 +988,11 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                     n_tests++;
                     if constexpr (SQ1)
                         park = true, park_x1 = x1, park_x2 = x2; // the term counts unless the test fails later
-                    else if (!visible<R, BRUTE>(S, ro, p, stk, hit_k))
-                        continue;
+                    else if constexpr (LIGHTS == 2)
+                    {
+                        if (!visible<R, BRUTE>(S, ro, p, stk, hit_k))
+                            continue;
+                    }
                 }
                 direct = direct + term;
             }
@@ -950,6 +1007,8 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 o = p, d = wi, prim = hit_k;
                 bounce++;
                 alive = true;
+                if constexpr (!BRUTE)
+                    trav_init(T, d), trav_done = false;
             }
             else
                 finished = true, fin_state = uint32_t(bounce + 1) << 16;
@@ -1011,15 +1070,15 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
 // The two precisions are separate kernels because their register budgets differ: the f64 tracer
 // runs 2 waves per SIMD (up to 256 vector registers) -- 3 (168 registers) when the visibility
 // tests are queued, which takes their live range out of the shading code -- the f32 tracer 4 (128).
-template <bool BRUTE, bool TAB, bool SQ1>
-__global__ void __launch_bounds__(BLOCK, SQ1 ? 3 : 2) k_trace_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
+template <bool BRUTE, bool TAB, int LIGHTS>
+__global__ void __launch_bounds__(BLOCK, LIGHTS == 1 ? 3 : 2) k_trace_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
 {
-    trace_body<double, BRUTE, TAB, SQ1>(S, cam, B, st, chunk);
+    trace_body<double, BRUTE, TAB, LIGHTS>(S, cam, B, st, chunk);
 }
-template <bool BRUTE, bool TAB, bool SQ1>
-__global__ void __launch_bounds__(BLOCK, 4) k_trace_f32(DScene<float> S, DCamera cam, DBatch B, DState<float> st, int chunk)
+template <bool BRUTE, bool TAB, int LIGHTS>
+__global__ void __launch_bounds__(BLOCK, BRUTE ? 4 : 3) k_trace_f32(DScene<float> S, DCamera cam, DBatch B, DState<float> st, int chunk)
 {
-    trace_body<float, BRUTE, TAB, SQ1>(S, cam, B, st, chunk);
+    trace_body<float, BRUTE, TAB, LIGHTS>(S, cam, B, st, chunk);
 }
 
 // one thread per pixel of the batch: continues the running per-pixel sum in sample order

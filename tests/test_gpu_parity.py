@@ -137,7 +137,8 @@ def test_render_f64_matches_golden_image(root, golden):
 
 
 @pytest.mark.parametrize("conf,w,h,spp", [("config/cbox.conf", 64, 64, 8), ("config/cbox_glossy.conf", 48, 48, 8),
-                                          ("config/cbox_cube.conf", 48, 48, 8), ("config/mis.conf", 96, 64, 4)])
+                                          ("config/cbox_cube.conf", 48, 48, 8), ("config/mis.conf", 96, 64, 4),
+                                          ("config/room.conf", 96, 64, 2)])
 def test_render_f64_matches_oracle(root, conf, w, h, spp):
     s, ref = load(root, conf, width=w, height=h, spp=spp)
     img, st = make_ctx(s).render(mode="f64", seed=13)
