@@ -296,7 +296,7 @@ void Context::build_accel(const Scene &sc)
     }
     static_assert(PLANE_REC_STRIDE == PQ_STRIDE, "record stride");
     bvh_ = Bvh();
-    build_bvh(sc.verts.data(), sc.n_tris(), bvh_, 4);
+    build_bvh(sc.verts.data(), sc.n_tris(), bvh_, bvh_leaf_tris);
     if (!brute_ && bvh_.max_depth + 2 > BVH_STACK)
         throw std::runtime_error("state: BVH deeper than the traversal stack");
     if (static_cast<int>(sc.mats.size()) > MAX_MATS)

@@ -11,6 +11,9 @@ spp = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 mode = sys.argv[4] if len(sys.argv) > 4 else "f64"
 scene = pt.Scene.load_conf(os.path.join(ROOT, conf), root_dir=ROOT, width=W, height=W, spp=spp)
 ctx = pt.Context(0)
+for kv in filter(None, os.environ.get('PTX_OPTS', '').split(',')):
+    k, v = kv.split('=')
+    ctx.set_option(k, int(v))
 ctx.build_accel(scene)
 print("accel", ctx.accel_info(), "tris", scene.info.n_tris, "lights", scene.info.n_lights, flush=True)
 out = torch.zeros((W, W, 3), dtype=torch.float64, device="cuda")
