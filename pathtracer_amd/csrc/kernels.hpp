@@ -277,30 +277,45 @@ template <class R> __device__ __forceinline__ bool bvh_step(const DScene<R> &S, 
     R e1 = box_entry(nd.lo1, nd.hi1, o, T.inv, R(-1e-6), tmax);
     int c0 = nd.c0, c1 = nd.c1;
     bool h0 = e0 > R(-1.5), h1 = e1 > R(-1.5);
-#pragma unroll
-    for (int side = 0; side < 2; side++)
-    {
-        int c = side == 0 ? c0 : c1;
-        bool h = side == 0 ? h0 : h1;
-        if (h && c < 0)
+    auto leaf_test = [&](const R *tri, int k, int face) {
+        R t;
+        if (tri_test(tri, o, d, t))
         {
-            int enc = ~c, first = enc >> 3, cnt = (enc & 7) + 1;
-            for (int k = first; k < first + cnt; k++)
+            V3<R> p = o + t * d;
+            R dist = norm(p - o);
+            if (dist > self_eps && (dist < T.best || (dist == T.best && face < T.best_face)))
             {
-                R t;
-                if (tri_test(S.tri_pre + (size_t)k * 12, o, d, t))
-                {
-                    V3<R> p = o + t * d;
-                    R dist = norm(p - o);
-                    int face = S.tri_face[k];
-                    if (dist > self_eps && (dist < T.best || (dist == T.best && face < T.best_face)))
-                    {
-                        T.best = dist;
-                        T.best_face = face;
-                        T.target = k;
-                        T.pt = p;
-                    }
-                }
+                T.best = dist;
+                T.best_face = face;
+                T.target = k;
+                T.pt = p;
+            }
+        }
+    };
+    const bool l0 = h0 && c0 < 0, l1 = h1 && c1 < 0;
+    if (l0 || l1)
+    {
+        // the first triangle of both leaf children is fetched in one go (one memory round trip
+        // instead of two); leaves hold a single triangle unless the builder was told otherwise
+        const int k0 = l0 ? (~c0 >> 3) : 0, k1 = l1 ? (~c1 >> 3) : 0;
+        R ta[12], tb[12];
+#pragma unroll
+        for (int q = 0; q < 12; q++)
+            ta[q] = S.tri_pre[(size_t)k0 * 12 + q], tb[q] = S.tri_pre[(size_t)k1 * 12 + q];
+        const int fa = S.tri_face[k0], fb = S.tri_face[k1];
+        if (l0)
+            leaf_test(ta, k0, fa);
+        if (l1)
+            leaf_test(tb, k1, fb);
+#pragma unroll
+        for (int side = 0; side < 2; side++)
+        {
+            const int c = side == 0 ? c0 : c1;
+            if (side == 0 ? l0 : l1)
+            {
+                const int enc = ~c, first = enc >> 3, cnt = (enc & 7) + 1;
+                for (int k = first + 1; k < first + cnt; k++)
+                    leaf_test(S.tri_pre + (size_t)k * 12, k, S.tri_face[k]);
             }
         }
     }
