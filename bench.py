@@ -102,6 +102,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     W = H = args.size
+    scene_name = os.path.splitext(os.path.basename(args.conf))[0]
+    headline = scene_name == "cbox" and args.size == 1024 and args.spp == 256
     scene = pt.Scene.load_conf(os.path.join(ROOT, args.conf), root_dir=ROOT, width=W, height=H, spp=args.spp)
     info = scene.info
     stream = torch.cuda.current_stream()
@@ -169,10 +171,12 @@ def main():
                     "design_bytes_per_launch": round(design_bytes), "design_achieved": round(design_gbs, 2),
                     "design_frac": round(design_gbs / HBM_PEAK_GBS, 5),
                     "note": "achieved prices the data streams of the algorithm (f32 SoA ray / hit / shadow / stack "
-                            "streams, 1718 B per path on this scene); the tracer keeps rays, hits and light samples "
+                            "streams, %.0f B per path on this scene); the tracer keeps rays, hits and light samples "
                             "in registers and LDS, so the bytes it must move (design_*) and the bytes it does move "
-                            "(traffic, PMC) are far below that, and it is bound by vector-ALU issue, see valu"}
-        cal = pmc_calibration(args.mode)
+                            "(traffic, PMC) are far below that, and it is bound by vector-ALU issue, see valu"
+                            % (stream_bytes * passes / max(ps["paths"], 1))}
+        # the committed counter calibration was collected on cbox; it says nothing about other scenes
+        cal = pmc_calibration(args.mode) if scene_name == "cbox" else None
         if cal and dom == "trace" and cal.get("paths_per_launch") == paths_per_step // world // passes:
             roofline["traffic"] = cal.get("hbm_bytes_per_launch")
             roofline["traffic_source"] = cal.get("source")
@@ -203,12 +207,14 @@ def main():
             cpu, checks = cpu_baseline_and_checks(ctx, args, W, H)
 
         result = {
-            "metric": "Mpaths/s at cbox 1024x1024 (whole job, all GPUs)", "value": round(value, 3), "unit": "Mpaths/s",
+            "metric": "Mpaths/s at %s %dx%d (whole job, all GPUs)" % (scene_name, W, H), "value": round(value, 3), "unit": "Mpaths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.mode, "data": "synthetic",
-            "config": {"workload": "cbox %dx%d, %d spp per GPU, depth %d, 26 triangles, 1 square light "
-                                   "(config/cbox.conf, the headline configuration)" % (W, H, args.spp, info.depth),
+            "config": {"workload": "%s %dx%d, %d spp per GPU, depth %d, %d triangles, %d lights (%d square) (%s%s)"
+                                   % (scene_name, W, H, args.spp, info.depth, info.n_tris, info.n_lights, info.n_square_lights,
+                                      args.conf, ", the headline configuration" if headline else ""),
+                       "intersector": "all-triangles (plane records)" if ctx.accel_info()["brute_force"] else "BVH",
                        "global_spp": spp_total, "paths_per_step": paths_per_step,
                        "sharding": "sample ranges per rank + RCCL reduce(sum) of the radiance sums to rank 0"},
             "mrays_per_s": round((st["segments"] + st["shadow_rays"]) * world * args.steps / dt / 1e6, 1),
@@ -244,8 +250,9 @@ def cpu_baseline_and_checks(ctx, args, W, H):
     oimg, ost = O.render(spp=spp, threads=threads, stats=True)
     cpu_dt = time.perf_counter() - t0
     cpu = {"value": round(W * H * spp / cpu_dt / 1e6, 4), "unit": "Mpaths/s", "cores": threads, "kind": "port",
-           "sample": "cbox %dx%d at %d spp (%.1f s, oracle/pt_oracle.c, OpenMP dynamic over rows, f64, all-triangles loop)"
-                     % (W, H, spp, cpu_dt)}
+           "sample": "%s %dx%d at %d spp (%.1f s, oracle/pt_oracle.c, OpenMP dynamic over rows, f64, %s)"
+                     % (os.path.splitext(os.path.basename(args.conf))[0], W, H, spp, cpu_dt,
+                        "BVH" if ref.verts.shape[0] > 256 else "all-triangles loop")}
     # gates: first-hit ids and the image at equal spp
     ids = ctx.first_hit()
     oids = O.first_hit()
