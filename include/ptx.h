@@ -136,7 +136,8 @@ void ptx_context_destroy(ptx_context *);
  * on any of them.  Set before ptx_build_accel. */
 int ptx_context_set_option(ptx_context *, const char *name, int64_t value);
 int ptx_build_accel(ptx_context *, const ptx_scene *);
-/* BVH statistics of the last build: n_nodes, n_leaves, max_depth, max_leaf_tris, brute_force flag */
+/* BVH statistics of the last build: n_nodes (4-wide), n_leaves (= triangles), max_depth, stack_need (most
+ * entries a traversal can hold on its stack), brute_force flag */
 int ptx_accel_info(const ptx_context *, int32_t *info5);
 
 /* ---- hot path ----------------------------------------------------------------------------------

@@ -159,7 +159,7 @@ class Context:
         a = np.zeros(5, dtype=np.int32)
         check(_lib.lib().ptx_accel_info(self._h, _ptr(a)))
         return dict(n_nodes=int(a[0]), n_leaves=int(a[1]), max_depth=int(a[2]),
-                    max_leaf_tris=int(a[3]), brute_force=bool(a[4]))
+                    stack_need=int(a[3]), brute_force=bool(a[4]))
 
     def generate_rays(self):
         n = self.width * self.height

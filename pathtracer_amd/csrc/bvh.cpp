@@ -1,4 +1,4 @@
-// Binned-SAH BVH builder (host).  Replaces the reference's accel builders
+// Binned-SAH BVH builder (host), collapsed to four children per node.  Replaces the reference's accel builders
 // (src/geometry/cAccelStruct.cpp:95-179 uniform grid, :291-482 octree) with a structure laid out
 // for the GPU; hit semantics stay those of the brute-force loops (src/geometry/cAccelStruct.cpp:28-87).
 #include "bvh.hpp"
@@ -47,13 +47,21 @@ struct Box
     }
 };
 
+// node of the binary tree the builder makes first
+struct Node2
+{
+    float lo0[3], hi0[3], lo1[3], hi1[3];
+    int32_t c0, c1; // >= 0: node index; < 0: leaf, ~c = (first << 3) | (count - 1)
+};
+
 struct Builder
 {
     const float *verts;
     std::vector<Box> tri_box;
     std::vector<double> centroid; // [F][3]
     std::vector<int32_t> order;
-    std::vector<BvhNode> nodes;
+    std::vector<Node2> nodes;
+    bool median = false;
     int max_leaf, n_leaves = 0, max_depth = 0, max_leaf_seen = 0;
     double pad_abs;
 
@@ -96,7 +104,12 @@ struct Builder
                 ext = cb.hi[k] - cb.lo[k], axis = k;
 
         int mid = first + count / 2;
-        if (ext > 0)
+        if (median)
+        {
+            std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
+                             [&](int32_t a, int32_t b) { return centroid[a * 3 + axis] < centroid[b * 3 + axis]; });
+        }
+        else if (ext > 0)
         {
             constexpr int NB = 16;
             Box bb[NB];
@@ -152,7 +165,7 @@ struct Builder
         {
             // degenerate (all centroids equal): split by index
             mid = first + count / 2;
-            if (count <= 8)
+            if (count <= 8 && max_leaf > 1)
                 return make_leaf(first, count);
         }
         int32_t me = static_cast<int32_t>(nodes.size());
@@ -160,11 +173,10 @@ struct Builder
         Box b0 = range_box(first, mid - first), b1 = range_box(mid, first + count - mid);
         int32_t c0 = build(first, mid - first, depth + 1);
         int32_t c1 = build(mid, first + count - mid, depth + 1);
-        BvhNode &nd = nodes[me];
+        Node2 &nd = nodes[me];
         store_box(b0, nd.lo0, nd.hi0);
         store_box(b1, nd.lo1, nd.hi1);
         nd.c0 = c0, nd.c1 = c1;
-        nd.pad[0] = nd.pad[1] = 0;
         return me;
     }
 
@@ -178,11 +190,10 @@ struct Builder
             int half = count / 2;
             Box b0 = range_box(first, half), b1 = range_box(first + half, count - half);
             int32_t c0 = make_leaf(first, half), c1 = make_leaf(first + half, count - half);
-            BvhNode &nd = nodes[me];
+            Node2 &nd = nodes[me];
             store_box(b0, nd.lo0, nd.hi0);
             store_box(b1, nd.lo1, nd.hi1);
             nd.c0 = c0, nd.c1 = c1;
-            nd.pad[0] = nd.pad[1] = 0;
             return me;
         }
         n_leaves++;
@@ -191,13 +202,91 @@ struct Builder
     }
 };
 
+
+// collapse of the binary tree into 4-wide nodes
+struct Collapser
+{
+    const std::vector<Node2> &src;
+    std::vector<BvhNode> out;
+    int max_depth = 0;
+
+    struct Slot
+    {
+        int32_t ref;
+        float lo[3], hi[3];
+        double area() const
+        {
+            double e0 = double(hi[0]) - lo[0], e1 = double(hi[1]) - lo[1], e2 = double(hi[2]) - lo[2];
+            return e0 * e1 + e1 * e2 + e2 * e0;
+        }
+    };
+    static void children(const Node2 &n, Slot &a, Slot &b)
+    {
+        a.ref = n.c0, b.ref = n.c1;
+        for (int k = 0; k < 3; k++)
+            a.lo[k] = n.lo0[k], a.hi[k] = n.hi0[k], b.lo[k] = n.lo1[k], b.hi[k] = n.hi1[k];
+    }
+
+    // returns the index of the 4-wide node made from binary node `n2`, and through `need` the
+    // stack entries a traversal of its subtree can hold at once
+    int32_t collapse(int32_t n2, int depth, int &need)
+    {
+        max_depth = std::max(max_depth, depth);
+        Slot slot[4];
+        int n = 2;
+        children(src[n2], slot[0], slot[1]);
+        while (n < 4)
+        {
+            int pick = -1;
+            double best = -1;
+            for (int i = 0; i < n; i++)
+                if (slot[i].ref >= 0 && slot[i].area() > best)
+                    best = slot[i].area(), pick = i;
+            if (pick < 0)
+                break;
+            const Node2 &c = src[slot[pick].ref];
+            children(c, slot[pick], slot[n]);
+            n++;
+        }
+        const int32_t me = static_cast<int32_t>(out.size());
+        out.emplace_back();
+        int deepest = 0;
+        int32_t ref[4];
+        for (int i = 0; i < n; i++)
+        {
+            if (slot[i].ref >= 0)
+            {
+                int sub = 0;
+                ref[i] = collapse(slot[i].ref, depth + 1, sub);
+                deepest = std::max(deepest, sub);
+            }
+            else
+                ref[i] = ~((~slot[i].ref) >> 3); // single-triangle leaf -> triangle child
+        }
+        BvhNode &nd = out[me];
+        std::memset(&nd, 0, sizeof(nd));
+        for (int i = 0; i < 4; i++)
+        {
+            nd.child[i] = i < n ? ref[i] : BVH_EMPTY;
+            for (int k = 0; k < 3; k++)
+            {
+                nd.lo[k][i] = i < n ? slot[i].lo[k] : std::numeric_limits<float>::infinity();
+                nd.hi[k][i] = i < n ? slot[i].hi[k] : std::numeric_limits<float>::infinity();
+            }
+        }
+        need = (n - 1) + deepest;
+        return me;
+    }
+};
+
 } // namespace
 
-void build_bvh(const float *verts, int n_tris, Bvh &out, int max_leaf_tris)
+void build_bvh(const float *verts, int n_tris, Bvh &out, bool median)
 {
     Builder B;
     B.verts = verts;
-    B.max_leaf = std::min(std::max(max_leaf_tris, 1), 8);
+    B.max_leaf = 1;
+    B.median = median;
     B.tri_box.resize(n_tris);
     B.centroid.resize(static_cast<size_t>(n_tris) * 3);
     B.order.resize(n_tris);
@@ -223,34 +312,39 @@ void build_bvh(const float *verts, int n_tris, Bvh &out, int max_leaf_tris)
     B.pad_abs = 1e-6 * (1.0 + max_abs);
 
     out = Bvh();
-    if (n_tris <= 0)
+    out.median = median;
+    out.n_leaves = std::max(n_tris, 0);
+    if (n_tris <= 1)
     {
+        // no tree to speak of: one node with at most one triangle child
         BvhNode nd;
         std::memset(&nd, 0, sizeof(nd));
-        for (int k = 0; k < 3; k++) // boxes at +infinity: the slab test can never enter them
-            nd.lo0[k] = nd.lo1[k] = nd.hi0[k] = nd.hi1[k] = std::numeric_limits<float>::infinity();
-        nd.c0 = nd.c1 = ~0;
+        for (int i = 0; i < 4; i++)
+        {
+            nd.child[i] = BVH_EMPTY;
+            for (int k = 0; k < 3; k++)
+                nd.lo[k][i] = nd.hi[k][i] = std::numeric_limits<float>::infinity();
+        }
+        if (n_tris == 1)
+        {
+            float lo[3], hi[3];
+            B.store_box(B.range_box(0, 1), lo, hi);
+            for (int k = 0; k < 3; k++)
+                nd.lo[k][0] = lo[k], nd.hi[k][0] = hi[k];
+            nd.child[0] = ~0;
+        }
         out.nodes.push_back(nd);
+        out.tri_order = std::move(B.order);
         return;
     }
-    int32_t root = B.build(0, n_tris, 0);
-    if (root < 0)
-    {
-        // whole scene fits one leaf: wrap it in a node whose second child is empty
-        BvhNode nd;
-        std::memset(&nd, 0, sizeof(nd));
-        B.store_box(B.range_box(0, n_tris), nd.lo0, nd.hi0);
-        for (int k = 0; k < 3; k++) // a box at +infinity: the slab test can never enter it
-            nd.lo1[k] = nd.hi1[k] = std::numeric_limits<float>::infinity();
-        nd.c0 = root;
-        nd.c1 = root; // never visited: its box is empty
-        B.nodes.push_back(nd);
-    }
-    out.nodes = std::move(B.nodes);
+    B.build(0, n_tris, 0); // n_tris >= 2 and single-triangle leaves: the root is binary node 0
+    Collapser C{B.nodes};
+    int need = 0;
+    C.collapse(0, 0, need);
+    out.nodes = std::move(C.out);
     out.tri_order = std::move(B.order);
-    out.n_leaves = B.n_leaves;
-    out.max_depth = B.max_depth;
-    out.max_leaf = B.max_leaf_seen;
+    out.max_depth = C.max_depth;
+    out.stack_need = need;
 }
 
 } // namespace ptx

@@ -1,5 +1,8 @@
-// Host-built, flattened 2-wide BVH (binned SAH).  One 64-byte node carries the boxes of BOTH
-// children, so a traversal step is one aligned 64-B fetch followed by two slab tests.
+// Host-built 4-wide BVH.  A binned-SAH binary tree with one triangle per leaf is built first and then
+// collapsed: every 4-wide node adopts grandchildren of the binary tree (largest box first) until
+// it has four children.  One 128-byte node carries the boxes of all its children, so a traversal
+// step is one aligned 128-B fetch followed by four slab tests; triangles are children like any
+// other (their box is the triangle's own), fetched and tested exactly when they are visited.
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -7,24 +10,29 @@
 namespace ptx
 {
 
-struct alignas(64) BvhNode
+constexpr int32_t BVH_EMPTY = INT32_MIN; // child slot without a child
+
+struct alignas(128) BvhNode
 {
-    float lo0[3], hi0[3]; // child 0 box (padded outward, float)
-    float lo1[3], hi1[3]; // child 1 box
-    int32_t c0, c1;       // >= 0: node index; < 0: leaf, ~c = (first << 3) | (count - 1), count <= 8
-    int32_t pad[2];
+    float lo[3][4], hi[3][4]; // child boxes by axis (padded outward, float)
+    int32_t child[4];         // >= 0: node index; BVH_EMPTY: none; other negatives: ~k, triangle k of tri_order
+    int32_t pad[4];
 };
-static_assert(sizeof(BvhNode) == 64, "BvhNode must be one 64-byte line");
+static_assert(sizeof(BvhNode) == 128, "BvhNode must be one 128-byte line");
 
 struct Bvh
 {
-    std::vector<BvhNode> nodes;    // nodes[0] is the root (a single-leaf scene gets one node)
+    std::vector<BvhNode> nodes;     // nodes[0] is the root
     std::vector<int32_t> tri_order; // ordered triangle k -> original face id
-    int n_leaves = 0, max_depth = 0, max_leaf = 0;
+    int n_leaves = 0;   // triangles referenced by the tree
+    int max_depth = 0;  // node levels below the root
+    int stack_need = 0; // most entries a near-first traversal can have on its stack
+    bool median = false; // built with median splits (the SAH tree was too deep for the stack)
 };
 
 // verts: [F][3][3] float.  Boxes are padded so that every hit the exact brute-force test could
 // accept (barycentric slack 1e-10, reconstruction rounding) lies strictly inside its leaf's box.
-void build_bvh(const float *verts, int n_tris, Bvh &out, int max_leaf_tris = 4);
+// median: split at the median of the longest axis instead of the SAH plane (a balanced tree).
+void build_bvh(const float *verts, int n_tris, Bvh &out, bool median = false);
 
 } // namespace ptx

@@ -324,8 +324,6 @@ int ptx_context_set_option(ptx_context *c, const char *name, int64_t value)
         c->ctx->brute_force_limit = static_cast<int>(value);
     else if (n == "default_batch_paths" && value > 0)
         c->ctx->default_batch_paths = value;
-    else if (n == "bvh_leaf_tris" && value >= 1 && value <= 8)
-        c->ctx->bvh_leaf_tris = static_cast<int>(value);
     else if (n == "shadow_queue" && (value == 0 || value == 1))
         c->ctx->shadow_queue = value != 0;
     else if (n == "trace_blocks_per_cu" && value >= 0 && value <= 64)
@@ -366,7 +364,7 @@ int ptx_accel_info(const ptx_context *c, int32_t *info5)
     }
     const ptx::Bvh &b = c->ctx->bvh();
     info5[0] = static_cast<int32_t>(b.nodes.size());
-    info5[1] = b.n_leaves, info5[2] = b.max_depth, info5[3] = b.max_leaf;
+    info5[1] = b.n_leaves, info5[2] = b.max_depth, info5[3] = b.stack_need;
     info5[4] = c->ctx->brute_force() ? 1 : 0;
     return PTX_OK;
 }

@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -63,6 +65,13 @@ template <class T> void upload(DeviceBuffer &b, const std::vector<T> &v, hipStre
 
 constexpr int MAX_TRACE_WAVES = 1 << 16; // rows of the per-wave statistics table
 
+// dynamic LDS of a BVH kernel (its traversal stacks); large requests must be announced
+template <class K> inline void allow_dynamic_lds(K kernel, size_t bytes)
+{
+    if (bytes > 0)
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+}
+
 inline unsigned blocks_for(int64_t n) { return static_cast<unsigned>(std::max<int64_t>(1, (n + BLOCK - 1) / BLOCK)); }
 
 } // namespace
@@ -71,6 +80,7 @@ inline unsigned blocks_for(int64_t n) { return static_cast<unsigned>(std::max<in
 template <class R> struct Context::Impl
 {
     DeviceBuffer tri_pre, mats, lights, tri_nrm;
+    DeviceBuffer bvh; // 4-wide BVH records (nodes, then the triangles of tri_pre)
     DeviceBuffer state_mem; // one slab carved into the DState arrays
     DState<R> st;
     int64_t capacity = 0;
@@ -103,6 +113,31 @@ template <class R> struct Context::Impl
             o[11] = t0 - t1;
         }
         upload(tri_pre, pre, s);
+
+        // 4-wide BVH records, 32 dwords each: nodes carry child boxes and child record ids,
+        // triangle records the 12 scalars above and the face id in dword 24
+        const size_t n_nodes = bvh.nodes.size();
+        std::vector<uint32_t> recs((n_nodes + static_cast<size_t>(std::max(F, 0))) * 32, 0u);
+        for (size_t i = 0; i < n_nodes; i++)
+        {
+            const BvhNode &nd = bvh.nodes[i];
+            uint32_t *o = &recs[i * 32];
+            std::memcpy(o, nd.lo, 48);
+            std::memcpy(o + 12, nd.hi, 48);
+            for (int j = 0; j < 4; j++)
+            {
+                const int32_t ch = nd.child[j];
+                o[24 + j] = ch == BVH_EMPTY ? 0xFFFFFFFFu : ch >= 0 ? static_cast<uint32_t>(ch) : static_cast<uint32_t>(n_nodes + static_cast<size_t>(~ch));
+            }
+        }
+        if (!brute)
+            for (int k = 0; k < F; k++)
+            {
+                uint32_t *o = &recs[(n_nodes + static_cast<size_t>(k)) * 32];
+                std::memcpy(o, &pre[static_cast<size_t>(k) * 12], 12 * sizeof(R));
+                o[24] = static_cast<uint32_t>(bvh.tri_order[k]);
+            }
+        upload(this->bvh, recs, s);
 
         std::vector<R> m(static_cast<size_t>(std::max<size_t>(sc.mats.size(), 1)) * MAT_STRIDE, R(0));
         for (size_t i = 0; i < sc.mats.size(); i++)
@@ -241,10 +276,11 @@ template <class R> struct Context::Impl
 
 struct Context::Geometry
 {
-    DeviceBuffer tri_face, tri_mat, verts, normals, mat_ids, nodes;
+    DeviceBuffer tri_face, tri_mat, verts, normals, mat_ids;
     DeviceBuffer tri_pq, rec_tri, tri_rec, rec_block; // plane records of the all-triangles intersector
     int n_recs = 0;
     float smax = 0.f;
+    int n_nodes = 0, id_bits = 1; // 4-wide BVH: node records, bits of the record id in a stack entry
 };
 
 Context::Context(int device) : device_(device)
@@ -296,9 +332,20 @@ void Context::build_accel(const Scene &sc)
     }
     static_assert(PLANE_REC_STRIDE == PQ_STRIDE, "record stride");
     bvh_ = Bvh();
-    build_bvh(sc.verts.data(), sc.n_tris(), bvh_, bvh_leaf_tris);
-    if (!brute_ && bvh_.max_depth + 2 > BVH_STACK)
+    build_bvh(sc.verts.data(), sc.n_tris(), bvh_);
+    if (!brute_ && bvh_.stack_need > BVH_STACK_MAX)
+        build_bvh(sc.verts.data(), sc.n_tris(), bvh_, /*median=*/true); // balanced tree: depth ~ log4 n
+    if (!brute_ && bvh_.stack_need > BVH_STACK_MAX)
         throw std::runtime_error("state: BVH deeper than the traversal stack");
+    {
+        // a stack entry keeps the record id in its low bits and the entry distance in the rest
+        const uint64_t n_rec = bvh_.nodes.size() + static_cast<uint64_t>(std::max(sc.n_tris(), 0));
+        id_bits_ = 1;
+        while ((uint64_t(1) << id_bits_) < n_rec)
+            id_bits_++;
+        if (id_bits_ > 24)
+            throw std::runtime_error("arg: scene too large (the BVH is limited to 2^24 nodes and triangles)");
+    }
     if (static_cast<int>(sc.mats.size()) > MAX_MATS)
         throw std::runtime_error("arg: at most 65534 materials are supported");
     if (sc.depth > 65535)
@@ -316,7 +363,6 @@ void Context::build_accel(const Scene &sc)
     upload(geo_->verts, sc.verts, s);
     upload(geo_->normals, sc.normals, s);
     upload(geo_->mat_ids, sc.mat_ids, s);
-    upload(geo_->nodes, bvh_.nodes, s);
     upload(geo_->tri_pq, pr.rec, s);
     upload(geo_->rec_tri, pr.rec_tri, s);
     upload(geo_->tri_rec, pr.tri_rec, s);
@@ -332,6 +378,8 @@ void Context::build_accel(const Scene &sc)
         upload(geo_->rec_block, blk, s);
     }
     geo_->n_recs = pr.n_recs;
+    geo_->n_nodes = static_cast<int>(bvh_.nodes.size());
+    geo_->id_bits = id_bits_;
     geo_->smax = pr.smax;
     f64_->build_tables(sc, bvh_, brute_, s);
     f32_->build_tables(sc, bvh_, brute_, s);
@@ -340,7 +388,7 @@ void Context::build_accel(const Scene &sc)
 }
 
 template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::Geometry &g, const void *tri_pre,
-                                                 const void *mats, const void *lights, const void *tri_nrm, bool brute)
+                                                 const void *mats, const void *lights, const void *tri_nrm, const void *bvh, bool brute)
 {
     DScene<R> S;
     S.n_tris = sc.n_tris();
@@ -366,7 +414,9 @@ template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::
     S.lights = static_cast<const R *>(lights);
     S.tri_nrm = static_cast<const R *>(tri_nrm);
     S.tri_mat = static_cast<const int32_t *>(g.tri_mat.p);
-    S.nodes = static_cast<const BvhNode *>(g.nodes.p);
+    S.bvh = static_cast<const uint4 *>(bvh);
+    S.n_nodes = g.n_nodes, S.id_bits = g.id_bits;
+    S.pad2_[0] = S.pad2_[1] = 0;
     return S;
 }
 
@@ -429,19 +479,25 @@ void Context::raycast(const double *ro, const double *rd, int64_t n, int32_t *id
     double *pp = pts ? static_cast<double *>(d_pts.p) : nullptr;
     if (mode == PTX_MODE_F64_)
     {
-        auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->mats.p, f64_->lights.p, f64_->tri_nrm.p, brute_);
+        auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->mats.p, f64_->lights.p, f64_->tri_nrm.p, f64_->bvh.p, brute_);
         if (brute_)
             hipLaunchKernelGGL((k_raycast<double, true>), grid, block, 0, s, S, cam, int(from_camera), po, pd, n, pi, pp);
         else
-            hipLaunchKernelGGL((k_raycast<double, false>), grid, block, 0, s, S, cam, int(from_camera), po, pd, n, pi, pp);
+        {
+            allow_dynamic_lds(k_raycast<double, false>, stack_bytes());
+            hipLaunchKernelGGL((k_raycast<double, false>), grid, block, stack_bytes(), s, S, cam, int(from_camera), po, pd, n, pi, pp);
+        }
     }
     else
     {
-        auto S = make_dscene<float>(scene_, *geo_, f32_->tri_pre.p, f32_->mats.p, f32_->lights.p, f32_->tri_nrm.p, brute_);
+        auto S = make_dscene<float>(scene_, *geo_, f32_->tri_pre.p, f32_->mats.p, f32_->lights.p, f32_->tri_nrm.p, f32_->bvh.p, brute_);
         if (brute_)
             hipLaunchKernelGGL((k_raycast<float, true>), grid, block, 0, s, S, cam, int(from_camera), po, pd, n, pi, pp);
         else
-            hipLaunchKernelGGL((k_raycast<float, false>), grid, block, 0, s, S, cam, int(from_camera), po, pd, n, pi, pp);
+        {
+            allow_dynamic_lds(k_raycast<float, false>, stack_bytes());
+            hipLaunchKernelGGL((k_raycast<float, false>), grid, block, stack_bytes(), s, S, cam, int(from_camera), po, pd, n, pi, pp);
+        }
     }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(ids, d_ids.p, n * 4, hipMemcpyDeviceToHost, s));
@@ -461,14 +517,17 @@ void Context::vistest(const double *p1, const double *p2, int64_t n, int32_t *vi
     d1.alloc(n * 24), d2.alloc(n * 24), dv.alloc(n * 4);
     HIP_CHECK(hipMemcpyAsync(d1.p, p1, n * 24, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemcpyAsync(d2.p, p2, n * 24, hipMemcpyHostToDevice, s));
-    auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->mats.p, f64_->lights.p, f64_->tri_nrm.p, brute_);
+    auto S = make_dscene<double>(scene_, *geo_, f64_->tri_pre.p, f64_->mats.p, f64_->lights.p, f64_->tri_nrm.p, f64_->bvh.p, brute_);
     const dim3 grid(blocks_for(n)), block(BLOCK);
     if (brute_)
         hipLaunchKernelGGL((k_vistest<double, true>), grid, block, 0, s, S, static_cast<const double *>(d1.p),
                            static_cast<const double *>(d2.p), n, static_cast<int32_t *>(dv.p));
     else
-        hipLaunchKernelGGL((k_vistest<double, false>), grid, block, 0, s, S, static_cast<const double *>(d1.p),
+    {
+        allow_dynamic_lds(k_vistest<double, false>, stack_bytes());
+        hipLaunchKernelGGL((k_vistest<double, false>), grid, block, stack_bytes(), s, S, static_cast<const double *>(d1.p),
                            static_cast<const double *>(d2.p), n, static_cast<int32_t *>(dv.p));
+    }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(vis, dv.p, n * 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -482,11 +541,13 @@ template <class R> struct TracePlan
 {
     void (*kernel)(DScene<R>, DCamera, DBatch, DState<R>, int) = nullptr;
     int blocks_per_cu = 1;
+    size_t dyn_lds = 0; // bytes of traversal stacks per workgroup (BVH kernels)
 };
 
-template <class R, bool BRUTE> static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shadow_queue)
+template <class R, bool BRUTE> static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shadow_queue, size_t dyn_lds)
 {
     TracePlan<R> p;
+    p.dyn_lds = dyn_lds;
     const bool tab = S.n_mats <= LDS_MATS && S.n_lights <= LDS_LIGHTS;
     // how visibility tests are compiled (see trace_body): none / parked in the LDS queue / in place
     const int lights = S.n_square == 0 ? 0 : ((BRUTE && S.n_lights == 1 && shadow_queue) ? 1 : 2);
@@ -511,9 +572,12 @@ template <class R, bool BRUTE> static TracePlan<R> plan_trace(const DScene<R> &S
         pick(std::true_type());
     else
         pick(std::false_type());
+    allow_dynamic_lds(p.kernel, dyn_lds);
     int per_cu = blocks_per_cu;
     if (per_cu <= 0)
-        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, p.kernel, BLOCK, 0));
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, p.kernel, BLOCK, dyn_lds));
+    if (std::getenv("PTX_DEBUG"))
+        std::fprintf(stderr, "[ptx] trace kernel: %d workgroups per CU, %zu bytes of dynamic LDS\n", per_cu, dyn_lds);
     p.blocks_per_cu = std::max(per_cu, 1);
     return p;
 }
@@ -526,7 +590,7 @@ static void launch_trace(const TracePlan<R> &plan, const DScene<R> &S, const DCa
     blocks = std::min<int64_t>(blocks, MAX_TRACE_WAVES / (BLOCK / 64));
     blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (B.n_paths + BLOCK - 1) / BLOCK));
     st.n_waves = static_cast<int>(blocks) * (BLOCK / 64);
-    hipLaunchKernelGGL(plan.kernel, dim3(static_cast<unsigned>(blocks)), dim3(BLOCK), 0, s, S, cam, B, st, chunk);
+    hipLaunchKernelGGL(plan.kernel, dim3(static_cast<unsigned>(blocks)), dim3(BLOCK), plan.dyn_lds, s, S, cam, B, st, chunk);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -631,11 +695,11 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     HIP_CHECK(hipMemsetAsync(im.st.stats, 0, sizeof(unsigned long long) * 8, s));
     HIP_CHECK(hipMemsetAsync(im.st.pool, 0, sizeof(unsigned int), s));
 
-    auto S = make_dscene<R>(sc, *geo_, im.tri_pre.p, im.mats.p, im.lights.p, im.tri_nrm.p, brute_);
+    auto S = make_dscene<R>(sc, *geo_, im.tri_pre.p, im.mats.p, im.lights.p, im.tri_nrm.p, im.bvh.p, brute_);
     DCamera cam = make_camera(sc);
     RenderTimers *tm = o.profile ? &timers_ : nullptr;
     // The grid of the tracer is just large enough to fill the device: its waves are persistent.
-    const TracePlan<R> plan = brute_ ? plan_trace<R, true>(S, trace_blocks_per_cu, shadow_queue) : plan_trace<R, false>(S, trace_blocks_per_cu, shadow_queue);
+    const TracePlan<R> plan = brute_ ? plan_trace<R, true>(S, trace_blocks_per_cu, shadow_queue, 0) : plan_trace<R, false>(S, trace_blocks_per_cu, shadow_queue, stack_bytes());
 
     hipEvent_t ev0, ev1;
     HIP_CHECK(hipEventCreate(&ev0));

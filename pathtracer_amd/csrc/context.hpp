@@ -69,6 +69,8 @@ public:
 
     const Bvh &bvh() const { return bvh_; }
     bool brute_force() const { return brute_; }
+    // LDS the traversal stacks of one workgroup of a BVH kernel take (0: all-triangles intersector)
+    size_t stack_bytes() const { return brute_ ? 0 : static_cast<size_t>(bvh_.stack_need > 1 ? bvh_.stack_need : 1) * 256 * 4; }
     const Scene &scene() const { return scene_; }
     bool has_scene() const { return have_scene_; }
 
@@ -76,7 +78,6 @@ public:
     int brute_force_limit = 64;
     int64_t default_batch_paths = int64_t(1) << 26;
     // largest number of triangles in a BVH leaf (1..8)
-    int bvh_leaf_tris = 1;
     // path ids a wave of the tracer takes from the pool at a time (>= 64)
     int chunk_paths = 64;
     // workgroups of the tracer per compute unit (<= 0: what the occupancy calculator reports)
@@ -96,6 +97,7 @@ private:
     void *stream_ = nullptr;
     Scene scene_;
     Bvh bvh_;
+    int id_bits_ = 1;
     bool brute_ = true, have_scene_ = false;
     Geometry *geo_ = nullptr;
     Impl<double> *f64_ = nullptr;

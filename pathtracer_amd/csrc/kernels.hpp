@@ -24,7 +24,7 @@ namespace ptx
 {
 
 constexpr int BLOCK = 256;      // threads per workgroup (4 waves)
-constexpr int BVH_STACK = 48;   // per-lane traversal stack entries (LDS)
+constexpr int BVH_STACK_MAX = 96; // most per-lane traversal stack entries (1 KB of LDS per entry and workgroup)
 constexpr int MAX_MATS = 0xFFFE; // the path state word keeps the tail material in 16 bits
 
 template <class R> struct DScene
@@ -45,7 +45,8 @@ template <class R> struct DScene
     const R *lights;           // [n_lights][LIGHT_STRIDE]
     const R *tri_nrm;          // [n_tris][4] intersector order: shading normal + flag (1: use it; 0: interpolate)
     const int32_t *tri_mat;    // [n_tris] intersector order: material id (-1: none)
-    const BvhNode *nodes;
+    const uint4 *bvh;          // [n_nodes + n_tris][8] 4-wide BVH records: nodes, then triangles in intersector order
+    int n_nodes, id_bits, pad2_[2]; // id_bits: bits of a stack entry that hold the record id
 };
 
 struct DCamera
@@ -93,19 +94,6 @@ template <class R> struct DState
 // ---------------------------------------------------------------------------------------------
 // intersectors
 // ---------------------------------------------------------------------------------------------
-template <class R> __device__ __forceinline__ R box_entry(const float *lo, const float *hi, V3<R> o, V3<R> inv, R t0, R t1)
-{
-    // slab test; returns entry distance or a negative "miss" marker (-2)
-    R ax = (R(lo[0]) - o.x) * inv.x, bx = (R(hi[0]) - o.x) * inv.x;
-    R ay = (R(lo[1]) - o.y) * inv.y, by = (R(hi[1]) - o.y) * inv.y;
-    R az = (R(lo[2]) - o.z) * inv.z, bz = (R(hi[2]) - o.z) * inv.z;
-    R tmin = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), t0));
-    R tmax = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), t1));
-    // widen by a few ulps so rounding can never cull a box the exact test would need
-    const R k = sizeof(R) == 8 ? R(1e-12) : R(1e-5);
-    return (tmin - fabs(tmin) * k - k <= tmax + fabs(tmax) * k + k) ? tmin : R(-2);
-}
-
 // ---------------------------------------------------------------------------------------------
 // two-phase all-triangles intersector.  Phase 1 walks a short list of f32 "plane records" in a
 // wave-uniform loop (records read through the scalar cache).  A record is the supporting plane of
@@ -143,6 +131,10 @@ template <class R> struct BruteLds
     uint32_t rec_block[BRUTE_MAX_RECS]; // potential blockers between record i and light 0
 };
 constexpr int LDS_WORDS_BRUTE = int(sizeof(BruteLds<double>) / 4);
+
+// BVH kernels: the traversal stacks, [levels][BLOCK] entries, sized at launch to what the scene's
+// tree can need
+extern __shared__ __align__(16) int dyn_stack[];
 
 // LDS scratch of the intersecting kernels: the tables above, or the per-lane BVH stacks
 template <class R, bool BRUTE> __device__ __forceinline__ int *intersector_scratch(const DScene<R> &S, int *lds)
@@ -250,96 +242,159 @@ __device__ __forceinline__ unsigned long long drop_own_plane(unsigned long long 
     return mask;
 }
 
-// State of one BVH closest-hit traversal, so that it can be advanced one node at a time.
+// ---------------------------------------------------------------------------------------------
+// 4-wide BVH.  The tree is one array of 128-byte records: nodes first (four child boxes by axis in
+// f32, four child record ids), then one record per triangle (its 12 scalars of the exact test in
+// R, its face id in dword 24).  A traversal step fetches ONE record and either runs four slab
+// tests (node) or the exact test (triangle), so every step costs one memory round trip whatever
+// mix of nodes and triangles the lanes of a wave are at.
+//
+// The slab tests run in f32 against an interval around the ray origin that contains the true origin
+// (rounding it to f32 moves it by at most 2^-24 of its magnitude; the interval is 2^-22 wide per
+// side) and only ever make a box look nearer and longer: entry distances are lower bounds, scaled
+// down by 2^-20 to absorb the roundings of the test itself, so a box that holds a triangle whose
+// exact distance could win or tie is never skipped, and hits, distances and ties are those of
+// testing every triangle exactly.
+//
+// Stack entries pack the (truncated, hence still lower-bound) entry distance above the record id
+// (S.id_bits bits): children are ordered by sorting their entries, and an entry whose distance has
+// fallen behind the closest hit is dropped when it is popped, without touching memory.
+// ---------------------------------------------------------------------------------------------
 template <class R> struct Trav
 {
-    int node, sp, target, best_face;
-    R best;
-    V3<R> pt, inv;
+    int cur;      // record to visit next
+    int sp, target, best_face;
+    R best;       // closest accepted distance so far (any-hit: length of the segment)
+    V3<R> pt;
+    float ohx, ohy, ohz, olx, oly, olz; // upper / lower end of the origin interval
+    float ivx, ivy, ivz;                // 1 / d, finite
 };
-template <class R> __device__ __forceinline__ void trav_init(Trav<R> &T, V3<R> d)
+template <class R> __device__ __forceinline__ void trav_init(Trav<R> &T, V3<R> o, V3<R> d, R limit = Consts<R>::big)
 {
-    T.node = 0, T.sp = 0, T.target = -1, T.best_face = 0x7fffffff;
-    T.best = Consts<R>::big;
+    T.cur = 0, T.sp = 0, T.target = -1, T.best_face = 0x7fffffff;
+    T.best = limit;
     T.pt = {R(0), R(0), R(0)};
-    T.inv = {R(1) / d.x, R(1) / d.y, R(1) / d.z};
+    const float fx = float(o.x), fy = float(o.y), fz = float(o.z);
+    const float P = 0x1p-22f * fmaxf(fmaxf(fabsf(fx), fabsf(fy)), fabsf(fz)) + 1e-30f;
+    T.ohx = fx + P, T.ohy = fy + P, T.ohz = fz + P;
+    T.olx = fx - P, T.oly = fy - P, T.olz = fz - P;
+    const float big = 3.0e38f; // an axis the ray does not move along: a huge finite slope keeps 0 * inf out of the slabs
+    T.ivx = __builtin_amdgcn_fmed3f(float(R(1) / d.x), -big, big);
+    T.ivy = __builtin_amdgcn_fmed3f(float(R(1) / d.y), -big, big);
+    T.ivz = __builtin_amdgcn_fmed3f(float(R(1) / d.z), -big, big);
 }
-// One node visit: slab tests of both children, exact tests of leaf triangles (winner = smallest
-// distance beyond self_eps, ties -> lowest face id), then near-first descent with the far child on
-// the lane's LDS stack stk[level * BLOCK].  Returns false once the traversal is complete.
-template <class R> __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, Trav<R> &T, int *stk)
+
+__device__ __forceinline__ void unpack_tri(double *tri, const uint4 &q0, const uint4 &q1, const uint4 &q2, const uint4 &q3,
+                                           const uint4 &q4, const uint4 &q5)
 {
+    tri[0] = __hiloint2double(int(q0.y), int(q0.x)), tri[1] = __hiloint2double(int(q0.w), int(q0.z));
+    tri[2] = __hiloint2double(int(q1.y), int(q1.x)), tri[3] = __hiloint2double(int(q1.w), int(q1.z));
+    tri[4] = __hiloint2double(int(q2.y), int(q2.x)), tri[5] = __hiloint2double(int(q2.w), int(q2.z));
+    tri[6] = __hiloint2double(int(q3.y), int(q3.x)), tri[7] = __hiloint2double(int(q3.w), int(q3.z));
+    tri[8] = __hiloint2double(int(q4.y), int(q4.x)), tri[9] = __hiloint2double(int(q4.w), int(q4.z));
+    tri[10] = __hiloint2double(int(q5.y), int(q5.x)), tri[11] = __hiloint2double(int(q5.w), int(q5.z));
+}
+__device__ __forceinline__ void unpack_tri(float *tri, const uint4 &q0, const uint4 &q1, const uint4 &q2, const uint4 &,
+                                           const uint4 &, const uint4 &)
+{
+    tri[0] = __uint_as_float(q0.x), tri[1] = __uint_as_float(q0.y), tri[2] = __uint_as_float(q0.z), tri[3] = __uint_as_float(q0.w);
+    tri[4] = __uint_as_float(q1.x), tri[5] = __uint_as_float(q1.y), tri[6] = __uint_as_float(q1.z), tri[7] = __uint_as_float(q1.w);
+    tri[8] = __uint_as_float(q2.x), tri[9] = __uint_as_float(q2.y), tri[10] = __uint_as_float(q2.z), tri[11] = __uint_as_float(q2.w);
+}
+
+// One record visit.  ANY = false: closest hit (winner = smallest distance beyond self_eps, ties ->
+// lowest face id; T.target = triangle, T.pt = point).  ANY = true: is the segment of length T.best
+// blocked (T.target = 1 and the traversal ends at the first blocker).  The lane's stack is
+// stk[level * BLOCK] in LDS.  Returns false once the traversal is complete.
+template <class R, bool ANY>
+__device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, Trav<R> &T, int *stk)
+{
+    constexpr float K = 0x1p-20f;
     const R self_eps = Consts<R>::self_eps;
-    const int lane_stride = BLOCK;
-    const BvhNode nd = S.nodes[T.node];
-    R tmax = T.best * (R(1) + (sizeof(R) == 8 ? R(1e-9) : R(1e-4))) + R(1e-9);
-    R e0 = box_entry(nd.lo0, nd.hi0, o, T.inv, R(-1e-6), tmax);
-    R e1 = box_entry(nd.lo1, nd.hi1, o, T.inv, R(-1e-6), tmax);
-    int c0 = nd.c0, c1 = nd.c1;
-    bool h0 = e0 > R(-1.5), h1 = e1 > R(-1.5);
-    auto leaf_test = [&](const R *tri, int k, int face) {
-        R t;
+    const uint4 *rec = S.bvh + (size_t)T.cur * 8;
+    const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
+    const int id_bits = S.id_bits;
+    uint32_t next = 0xFFFFFFFFu;
+    if (T.cur >= S.n_nodes)
+    {
+        R tri[12], t;
+        unpack_tri(tri, q0, q1, q2, q3, q4, q5);
         if (tri_test(tri, o, d, t))
         {
-            V3<R> p = o + t * d;
-            R dist = norm(p - o);
-            if (dist > self_eps && (dist < T.best || (dist == T.best && face < T.best_face)))
+            if (ANY)
             {
-                T.best = dist;
-                T.best_face = face;
-                T.target = k;
-                T.pt = p;
+                if (t < T.best - self_eps && t > self_eps)
+                {
+                    T.target = 1;
+                    return false;
+                }
             }
-        }
-    };
-    const bool l0 = h0 && c0 < 0, l1 = h1 && c1 < 0;
-    if (l0 || l1)
-    {
-        // the first triangle of both leaf children is fetched in one go (one memory round trip
-        // instead of two); leaves hold a single triangle unless the builder was told otherwise
-        const int k0 = l0 ? (~c0 >> 3) : 0, k1 = l1 ? (~c1 >> 3) : 0;
-        R ta[12], tb[12];
-#pragma unroll
-        for (int q = 0; q < 12; q++)
-            ta[q] = S.tri_pre[(size_t)k0 * 12 + q], tb[q] = S.tri_pre[(size_t)k1 * 12 + q];
-        const int fa = S.tri_face[k0], fb = S.tri_face[k1];
-        if (l0)
-            leaf_test(ta, k0, fa);
-        if (l1)
-            leaf_test(tb, k1, fb);
-#pragma unroll
-        for (int side = 0; side < 2; side++)
-        {
-            const int c = side == 0 ? c0 : c1;
-            if (side == 0 ? l0 : l1)
+            else
             {
-                const int enc = ~c, first = enc >> 3, cnt = (enc & 7) + 1;
-                for (int k = first + 1; k < first + cnt; k++)
-                    leaf_test(S.tri_pre + (size_t)k * 12, k, S.tri_face[k]);
+                const int face = int(q6.x);
+                V3<R> p = o + t * d;
+                R dist = norm(p - o);
+                if (dist > self_eps && (dist < T.best || (dist == T.best && face < T.best_face)))
+                {
+                    T.best = dist;
+                    T.best_face = face;
+                    T.target = T.cur - S.n_nodes;
+                    T.pt = p;
+                }
             }
         }
     }
-    bool i0 = h0 && c0 >= 0, i1 = h1 && c1 >= 0;
-    if (i0 && i1)
-    {
-        int near = e0 <= e1 ? c0 : c1, far = e0 <= e1 ? c1 : c0;
-        if (T.sp < BVH_STACK)
-            stk[T.sp * lane_stride] = far;
-        T.sp++;
-        T.node = near;
-    }
-    else if (i0)
-        T.node = c0;
-    else if (i1)
-        T.node = c1;
     else
     {
-        if (T.sp == 0)
-            return false;
-        T.sp--;
-        T.node = stk[T.sp * lane_stride];
+        const float tmaxf = float(T.best) * (1.0f + K) + 1e-30f;
+        auto slab = [&](uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint32_t hy, uint32_t hz, uint32_t child) {
+            const float ax = (__uint_as_float(lx) - T.ohx) * T.ivx, bx = (__uint_as_float(hx) - T.olx) * T.ivx;
+            const float ay = (__uint_as_float(ly) - T.ohy) * T.ivy, by = (__uint_as_float(hy) - T.oly) * T.ivy;
+            const float az = (__uint_as_float(lz) - T.ohz) * T.ivz, bz = (__uint_as_float(hz) - T.olz) * T.ivz;
+            float tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), 0.0f);
+            const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            tn = fmaf(-K, tn, tn); // a lower bound of the true entry distance
+            const bool hit = (tn <= fmaf(K, fabsf(tf), tf)) & (tn <= tmaxf) & (child != 0xFFFFFFFFu);
+            return hit ? (((__float_as_uint(tn) >> (id_bits - 1)) << id_bits) | child) : 0xFFFFFFFFu;
+        };
+        uint32_t k0 = slab(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, q6.x);
+        uint32_t k1 = slab(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, q6.y);
+        uint32_t k2 = slab(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, q6.z);
+        uint32_t k3 = slab(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, q6.w);
+        auto order = [](uint32_t &a, uint32_t &b) {
+            const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+            a = lo, b = hi;
+        };
+        order(k0, k1), order(k2, k3), order(k0, k2), order(k1, k3), order(k1, k2);
+        // nearest child next, the others on the stack, farthest first (the host has checked that
+        // the tree cannot overflow the stack)
+        if (k1 != 0xFFFFFFFFu)
+        {
+            if (k3 != 0xFFFFFFFFu)
+                stk[(T.sp++) * BLOCK] = int(k3);
+            if (k2 != 0xFFFFFFFFu)
+                stk[(T.sp++) * BLOCK] = int(k2);
+            stk[(T.sp++) * BLOCK] = int(k1);
+        }
+        next = k0;
     }
-    return true;
+    const uint32_t id_mask = (1u << id_bits) - 1u;
+    if (next != 0xFFFFFFFFu)
+    {
+        T.cur = int(next & id_mask);
+        return true;
+    }
+    const float tmaxf = float(T.best) * (1.0f + K) + 1e-30f;
+    while (T.sp > 0)
+    {
+        const uint32_t e = uint32_t(stk[(--T.sp) * BLOCK]);
+        if (__uint_as_float((e >> id_bits) << (id_bits - 1)) <= tmaxf)
+        {
+            T.cur = int(e & id_mask);
+            return true;
+        }
+    }
+    return false;
 }
 
 // closest hit.  Returns the intersector-order triangle index (or -1) and the hit point.
@@ -415,8 +470,8 @@ __device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d,
         return target;
     }
     Trav<R> T;
-    trav_init(T, d);
-    while (bvh_step(S, o, d, T, stk))
+    trav_init(T, o, d);
+    while (bvh_step<R, false>(S, o, d, T, stk))
     {
     }
     pt = T.pt;
@@ -452,53 +507,12 @@ __device__ __forceinline__ bool visible(const DScene<R> &S, V3<R> p1, V3<R> p2, 
         }
         return !blocked;
     }
-    V3<R> inv = {R(1) / dir.x, R(1) / dir.y, R(1) / dir.z};
-    int sp = 0, node = 0;
-    const int lane_stride = BLOCK;
-    for (;;)
+    Trav<R> T;
+    trav_init(T, p1, dir, dist);
+    while (bvh_step<R, true>(S, p1, dir, T, stk))
     {
-        const BvhNode nd = S.nodes[node];
-        R e0 = box_entry(nd.lo0, nd.hi0, p1, inv, R(-1e-6), dist);
-        R e1 = box_entry(nd.lo1, nd.hi1, p1, inv, R(-1e-6), dist);
-        int c0 = nd.c0, c1 = nd.c1;
-        bool h0 = e0 > R(-1.5), h1 = e1 > R(-1.5);
-#pragma unroll
-        for (int side = 0; side < 2; side++)
-        {
-            int c = side == 0 ? c0 : c1;
-            bool h = side == 0 ? h0 : h1;
-            if (h && c < 0)
-            {
-                int enc = ~c, first = enc >> 3, cnt = (enc & 7) + 1;
-                for (int k = first; k < first + cnt; k++)
-                {
-                    R t;
-                    if (tri_test(S.tri_pre + (size_t)k * 12, p1, dir, t) && t < dist - self_eps && t > self_eps)
-                        return false;
-                }
-            }
-        }
-        bool i0 = h0 && c0 >= 0, i1 = h1 && c1 >= 0;
-        if (i0 && i1)
-        {
-            if (sp < BVH_STACK)
-                stk[sp * lane_stride] = c1;
-            sp++;
-            node = c0;
-        }
-        else if (i0)
-            node = c0;
-        else if (i1)
-            node = c1;
-        else
-        {
-            if (sp == 0)
-                break;
-            sp--;
-            node = stk[sp * lane_stride];
-        }
     }
-    return true;
+    return T.target < 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -544,8 +558,8 @@ __global__ void __launch_bounds__(BLOCK)
     k_raycast(DScene<R> S, DCamera cam, int from_camera, const double *__restrict__ ro, const double *__restrict__ rd,
               int64_t n, int32_t *__restrict__ face_ids, double *__restrict__ pts)
 {
-    __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : BVH_STACK * BLOCK];
-    int *stk = intersector_scratch<R, BRUTE>(S, lds_raw); // all threads: contains a barrier
+    __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : 1];
+    int *stk = intersector_scratch<R, BRUTE>(S, BRUTE ? lds_raw : dyn_stack); // all threads: contains a barrier
     int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n)
         return;
@@ -573,8 +587,8 @@ template <class R, bool BRUTE>
 __global__ void __launch_bounds__(BLOCK)
     k_vistest(DScene<R> S, const double *__restrict__ p1, const double *__restrict__ p2, int64_t n, int32_t *__restrict__ vis)
 {
-    __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : BVH_STACK * BLOCK];
-    int *stk = intersector_scratch<R, BRUTE>(S, lds_raw); // all threads: contains a barrier
+    __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : 1];
+    int *stk = intersector_scratch<R, BRUTE>(S, BRUTE ? lds_raw : dyn_stack); // all threads: contains a barrier
     int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n)
         return;
@@ -647,7 +661,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
 {
     constexpr bool NRM = BRUTE; // all-triangles intersector = at most 64 triangles: the per-triangle tables fit LDS
     constexpr bool SQ1 = LIGHTS == 1;
-    __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : BVH_STACK * BLOCK];
+    __shared__ __align__(16) int lds_raw[BRUTE ? LDS_WORDS_BRUTE : 1];
     __shared__ R lds_mats[TAB ? LDS_MATS * MAT_STRIDE : 1];
     __shared__ R lds_lights[TAB ? (SQ1 ? 1 : LDS_LIGHTS) * LIGHT_STRIDE : 1];
     __shared__ R lds_nrm[NRM ? LDS_TRIS * 4 : 1];
@@ -669,7 +683,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         for (int k = threadIdx.x; k < S.n_tris; k += BLOCK)
             lds_tmat[k] = S.tri_mat[k];
     }
-    int *stk = intersector_scratch<R, BRUTE>(S, lds_raw);
+    int *stk = intersector_scratch<R, BRUTE>(S, BRUTE ? lds_raw : dyn_stack);
     __syncthreads(); // the only barrier: from here on the waves of the workgroup are independent
     const int g = global_wave(), lane = lane_id();
     if (g >= st.n_waves)
@@ -694,7 +708,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
     bool alive = false;
     bool trav_done = false; // BVH: the lane's closest-hit traversal is complete (its path waits for shading)
     Trav<R> T;
-    trav_init(T, V3<R>{R(1), R(1), R(1)});
+    trav_init(T, V3<R>{R(0), R(0), R(0)}, V3<R>{R(1), R(1), R(1)});
     V3<R> o = {R(0), R(0), R(0)}, d = {R(0), R(0), R(0)};
     uint32_t pid = 0, sample = 0;
     int bounce = 0, prim = -1;
@@ -843,7 +857,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 if (n_serve >= 32 || (n_serve > 0 && n_trav <= n_serve))
                     break;
                 if (alive && !trav_done)
-                    trav_done = !bvh_step(S, o, d, T, stk);
+                    trav_done = !bvh_step<R, false>(S, o, d, T, stk);
             }
         }
         // ---- idle lanes start the next paths ------------------------------------------------------
@@ -892,7 +906,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 bounce = 0, prim = -1;
                 alive = true;
                 if constexpr (!BRUTE)
-                    trav_init(T, d), trav_done = false;
+                    trav_init(T, o, d), trav_done = false;
             }
         }
         {
@@ -1023,7 +1037,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 bounce++;
                 alive = true;
                 if constexpr (!BRUTE)
-                    trav_init(T, d), trav_done = false;
+                    trav_init(T, o, d), trav_done = false;
             }
             else
                 finished = true, fin_state = uint32_t(bounce + 1) << 16;
