@@ -165,8 +165,6 @@ struct Builder
         {
             // degenerate (all centroids equal): split by index
             mid = first + count / 2;
-            if (count <= 8 && max_leaf > 1)
-                return make_leaf(first, count);
         }
         int32_t me = static_cast<int32_t>(nodes.size());
         nodes.emplace_back();
@@ -203,22 +201,27 @@ struct Builder
 };
 
 
-// collapse of the binary tree into 4-wide nodes
+// collapse of the binary tree into 4-wide nodes.  The binary tree ends in leaves of up to four
+// triangles; a 4-wide node adopts, largest box first, the children of its inner children and the
+// triangles of its leaf children while it has room, and a leaf that is left over becomes a node of
+// triangle children itself.
 struct Collapser
 {
-    const std::vector<Node2> &src;
+    const Builder &B;
     std::vector<BvhNode> out;
     int max_depth = 0;
 
     struct Slot
     {
-        int32_t ref;
+        int32_t ref; // >= 0: binary node; < 0: leaf, ~ref = (first << 3) | (count - 1)
         float lo[3], hi[3];
         double area() const
         {
             double e0 = double(hi[0]) - lo[0], e1 = double(hi[1]) - lo[1], e2 = double(hi[2]) - lo[2];
             return e0 * e1 + e1 * e2 + e2 * e0;
         }
+        int leaf_first() const { return (~ref) >> 3; }
+        int leaf_count() const { return ((~ref) & 7) + 1; }
     };
     static void children(const Node2 &n, Slot &a, Slot &b)
     {
@@ -226,43 +229,16 @@ struct Collapser
         for (int k = 0; k < 3; k++)
             a.lo[k] = n.lo0[k], a.hi[k] = n.hi0[k], b.lo[k] = n.lo1[k], b.hi[k] = n.hi1[k];
     }
-
-    // returns the index of the 4-wide node made from binary node `n2`, and through `need` the
-    // stack entries a traversal of its subtree can hold at once
-    int32_t collapse(int32_t n2, int depth, int &need)
+    Slot triangle(int k) const
     {
-        max_depth = std::max(max_depth, depth);
-        Slot slot[4];
-        int n = 2;
-        children(src[n2], slot[0], slot[1]);
-        while (n < 4)
-        {
-            int pick = -1;
-            double best = -1;
-            for (int i = 0; i < n; i++)
-                if (slot[i].ref >= 0 && slot[i].area() > best)
-                    best = slot[i].area(), pick = i;
-            if (pick < 0)
-                break;
-            const Node2 &c = src[slot[pick].ref];
-            children(c, slot[pick], slot[n]);
-            n++;
-        }
-        const int32_t me = static_cast<int32_t>(out.size());
-        out.emplace_back();
-        int deepest = 0;
-        int32_t ref[4];
-        for (int i = 0; i < n; i++)
-        {
-            if (slot[i].ref >= 0)
-            {
-                int sub = 0;
-                ref[i] = collapse(slot[i].ref, depth + 1, sub);
-                deepest = std::max(deepest, sub);
-            }
-            else
-                ref[i] = ~((~slot[i].ref) >> 3); // single-triangle leaf -> triangle child
-        }
+        Slot s;
+        s.ref = ~static_cast<int32_t>((k << 3) | 0);
+        B.store_box(B.tri_box[B.order[k]], s.lo, s.hi);
+        return s;
+    }
+
+    void emit(int32_t me, const Slot *slot, const int32_t *ref, int n)
+    {
         BvhNode &nd = out[me];
         std::memset(&nd, 0, sizeof(nd));
         for (int i = 0; i < 4; i++)
@@ -274,6 +250,79 @@ struct Collapser
                 nd.hi[k][i] = i < n ? slot[i].hi[k] : std::numeric_limits<float>::infinity();
             }
         }
+    }
+
+    // a node whose children are the triangles of one leaf
+    int32_t leaf_node(const Slot &leaf, int depth, int &need)
+    {
+        max_depth = std::max(max_depth, depth);
+        const int32_t me = static_cast<int32_t>(out.size());
+        out.emplace_back();
+        Slot slot[4];
+        int32_t ref[4];
+        const int n = leaf.leaf_count(); // <= 4
+        for (int i = 0; i < n; i++)
+        {
+            slot[i] = triangle(leaf.leaf_first() + i);
+            ref[i] = ~static_cast<int32_t>(leaf.leaf_first() + i);
+        }
+        emit(me, slot, ref, n);
+        need = n - 1;
+        return me;
+    }
+
+    // returns the index of the 4-wide node made from `slot[0 .. n)`, and through `need` the stack
+    // entries a traversal of its subtree can hold at once
+    int32_t collapse(Slot *slot, int n, int depth, int &need)
+    {
+        max_depth = std::max(max_depth, depth);
+        while (n < 4)
+        {
+            int pick = -1;
+            double best = -1;
+            for (int i = 0; i < n; i++)
+            {
+                const bool inner = slot[i].ref >= 0;
+                const bool open_leaf = !inner && slot[i].leaf_count() > 1 && n - 1 + slot[i].leaf_count() <= 4;
+                if ((inner || open_leaf) && slot[i].area() > best)
+                    best = slot[i].area(), pick = i;
+            }
+            if (pick < 0)
+                break;
+            if (slot[pick].ref >= 0)
+            {
+                const Node2 &c = B.nodes[slot[pick].ref];
+                children(c, slot[pick], slot[n]);
+                n++;
+            }
+            else
+            {
+                const int first = slot[pick].leaf_first(), cnt = slot[pick].leaf_count();
+                slot[pick] = triangle(first);
+                for (int i = 1; i < cnt; i++)
+                    slot[n++] = triangle(first + i);
+            }
+        }
+        const int32_t me = static_cast<int32_t>(out.size());
+        out.emplace_back();
+        int deepest = 0;
+        int32_t ref[4];
+        for (int i = 0; i < n; i++)
+        {
+            int sub = 0;
+            if (slot[i].ref >= 0)
+            {
+                Slot sub_slot[4];
+                children(B.nodes[slot[i].ref], sub_slot[0], sub_slot[1]);
+                ref[i] = collapse(sub_slot, 2, depth + 1, sub);
+            }
+            else if (slot[i].leaf_count() > 1)
+                ref[i] = leaf_node(slot[i], depth + 1, sub);
+            else
+                ref[i] = ~static_cast<int32_t>(slot[i].leaf_first());
+            deepest = std::max(deepest, sub);
+        }
+        emit(me, slot, ref, n);
         need = (n - 1) + deepest;
         return me;
     }
@@ -285,7 +334,7 @@ void build_bvh(const float *verts, int n_tris, Bvh &out, bool median)
 {
     Builder B;
     B.verts = verts;
-    B.max_leaf = 1;
+    B.max_leaf = 4;
     B.median = median;
     B.tri_box.resize(n_tris);
     B.centroid.resize(static_cast<size_t>(n_tris) * 3);
@@ -314,33 +363,27 @@ void build_bvh(const float *verts, int n_tris, Bvh &out, bool median)
     out = Bvh();
     out.median = median;
     out.n_leaves = std::max(n_tris, 0);
-    if (n_tris <= 1)
-    {
-        // no tree to speak of: one node with at most one triangle child
-        BvhNode nd;
-        std::memset(&nd, 0, sizeof(nd));
-        for (int i = 0; i < 4; i++)
-        {
-            nd.child[i] = BVH_EMPTY;
-            for (int k = 0; k < 3; k++)
-                nd.lo[k][i] = nd.hi[k][i] = std::numeric_limits<float>::infinity();
-        }
-        if (n_tris == 1)
-        {
-            float lo[3], hi[3];
-            B.store_box(B.range_box(0, 1), lo, hi);
-            for (int k = 0; k < 3; k++)
-                nd.lo[k][0] = lo[k], nd.hi[k][0] = hi[k];
-            nd.child[0] = ~0;
-        }
-        out.nodes.push_back(nd);
-        out.tri_order = std::move(B.order);
-        return;
-    }
-    B.build(0, n_tris, 0); // n_tris >= 2 and single-triangle leaves: the root is binary node 0
-    Collapser C{B.nodes};
+    Collapser C{B};
     int need = 0;
-    C.collapse(0, 0, need);
+    if (n_tris <= 0)
+    {
+        C.out.emplace_back();
+        C.emit(0, nullptr, nullptr, 0); // a root without children
+    }
+    else if (n_tris <= 4)
+    {
+        // no tree to speak of: one node whose children are the triangles
+        Collapser::Slot all;
+        all.ref = ~static_cast<int32_t>(n_tris - 1);
+        C.leaf_node(all, 0, need);
+    }
+    else
+    {
+        B.build(0, n_tris, 0); // more triangles than a leaf holds: the root is binary node 0
+        Collapser::Slot top[4];
+        Collapser::children(B.nodes[0], top[0], top[1]);
+        C.collapse(top, 2, 0, need);
+    }
     out.nodes = std::move(C.out);
     out.tri_order = std::move(B.order);
     out.max_depth = C.max_depth;
