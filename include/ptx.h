@@ -119,6 +119,13 @@ const char *ptx_scene_result_path(const ptx_scene *);
  * light and it is a square light.  Null outputs are skipped. */
 int ptx_scene_plane_records(const ptx_scene *, int32_t *n_records, int32_t *n_pairs,
                             int32_t *rec_tri64, uint32_t *blockers32);
+/* Builds the 4-wide BVH of the scene on the host (the structure that replaces the reference's grid
+ * and octree, src/geometry/cAccelStruct.cpp:95-482, for scenes too large for the all-triangles
+ * intersector) and checks it, for inspection and tests: info6 = number of nodes, number of
+ * children, depth, stack bound, triangle references, violations (a child box outside its parent's,
+ * a vertex outside its triangle's box, a triangle referenced other than once, a path through the
+ * tree that can exceed the stack bound).  median != 0: median splits instead of SAH. */
+int ptx_scene_bvh_check(const ptx_scene *, int32_t median, int64_t *info6);
 
 /* ---- context / accel -------------------------------------------------------------------------
  * ptx_context_create + ptx_build_accel replace cPathTracer::Init (src/tracing/cPathTracer.cpp:20-57)

@@ -59,6 +59,7 @@ SYMBOLS = {
     "ptx_scene_copy_camera": (C.c_int, [_VP, _VP, _VP, _VP]),
     "ptx_scene_result_path": (C.c_char_p, [_VP]),
     "ptx_scene_plane_records": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "ptx_scene_bvh_check": (C.c_int, [_VP, C.c_int32, _VP]),
     "ptx_context_create": (C.c_int, [C.c_int32, C.POINTER(_VP)]),
     "ptx_context_set_stream": (C.c_int, [_VP, _VP]),
     "ptx_context_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int64]),

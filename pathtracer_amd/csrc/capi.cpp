@@ -7,6 +7,7 @@
 #include <cstring>
 #include <new>
 #include <stdexcept>
+#include <algorithm>
 #include <string>
 
 struct ptx_scene
@@ -283,6 +284,94 @@ int ptx_scene_plane_records(const ptx_scene *s, int32_t *n_records, int32_t *n_p
         for (int k = 0; k < 32; k++)
             blockers32[k] = blk[k];
     }
+    return PTX_OK;
+    PTX_CATCH
+}
+
+int ptx_scene_bvh_check(const ptx_scene *s, int32_t median, int64_t *info6)
+{
+    if (!s || !info6)
+        return fail_arg("ptx_scene_bvh_check: null argument");
+    PTX_TRY
+    const ptx::Scene &sc = s->sc;
+    ptx::Bvh b;
+    ptx::build_bvh(sc.verts.data(), sc.n_tris(), b, median != 0);
+    const int F = sc.n_tris();
+    std::vector<int> seen(std::max(F, 1), 0);
+    int64_t children = 0, violations = 0;
+    // walk the tree: every child box must lie inside its parent's box for that child, every
+    // triangle's vertices inside the box stored with it, and the stack bound must hold on every path
+    struct Item { int32_t node; float lo[3], hi[3]; int depth_need; bool has_box; };
+    std::vector<Item> todo;
+    Item root{};
+    root.node = 0, root.has_box = false, root.depth_need = 0;
+    todo.push_back(root);
+    int64_t worst_need = 0;
+    while (!todo.empty())
+    {
+        Item it = todo.back();
+        todo.pop_back();
+        const ptx::BvhNode &nd = b.nodes[it.node];
+        int n = 0;
+        for (int i = 0; i < 4; i++)
+            n += nd.child[i] != ptx::BVH_EMPTY;
+        const int here = it.depth_need + std::max(n - 1, 0);
+        worst_need = std::max<int64_t>(worst_need, here);
+        for (int i = 0; i < 4; i++)
+        {
+            const int32_t ch = nd.child[i];
+            if (ch == ptx::BVH_EMPTY)
+                continue;
+            children++;
+            if (it.has_box)
+                for (int k = 0; k < 3; k++)
+                    if (nd.lo[k][i] < it.lo[k] || nd.hi[k][i] > it.hi[k])
+                        violations++;
+            if (ch >= 0)
+            {
+                Item c{};
+                c.node = ch, c.has_box = true, c.depth_need = here;
+                for (int k = 0; k < 3; k++)
+                    c.lo[k] = nd.lo[k][i], c.hi[k] = nd.hi[k][i];
+                todo.push_back(c);
+            }
+            else
+            {
+                const int k_tri = ~ch;
+                if (k_tri < 0 || k_tri >= F)
+                {
+                    violations++;
+                    continue;
+                }
+                seen[k_tri]++;
+                const float *v = &sc.verts[static_cast<size_t>(b.tri_order[k_tri]) * 9];
+                for (int j = 0; j < 3; j++)
+                    for (int k = 0; k < 3; k++)
+                        if (!(v[j * 3 + k] > nd.lo[k][i] && v[j * 3 + k] < nd.hi[k][i]))
+                            violations++;
+            }
+        }
+    }
+    int64_t refs = 0;
+    for (int k = 0; k < F; k++)
+    {
+        refs += seen[k];
+        if (seen[k] != 1)
+            violations++;
+    }
+    std::vector<int> perm(b.tri_order.begin(), b.tri_order.end());
+    std::sort(perm.begin(), perm.end());
+    for (int k = 0; k < F; k++)
+        if (perm[k] != k)
+            violations++;
+    if (worst_need > b.stack_need)
+        violations++;
+    info6[0] = static_cast<int64_t>(b.nodes.size());
+    info6[1] = children;
+    info6[2] = b.max_depth;
+    info6[3] = b.stack_need;
+    info6[4] = refs;
+    info6[5] = violations;
     return PTX_OK;
     PTX_CATCH
 }
