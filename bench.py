@@ -49,12 +49,15 @@ def reference_stream_bytes(st, n_square):
     """Bytes per launch under the accounting that prices the reference algorithm's data streams
     (f32 SoA, per path segment: ray write+read 48, hit record write+read 32, 72 of triangle
     attributes, 24 pushed on the stack, 64 per shadow ray; per path: 24 read back per segment at
-    the resolve + 12 accumulated; scene data LDS-resident): B_seg = 176 + 64 * N_shadow,
-    B_path = segments/path * (B_seg + 24) + 12.  The tracer here is designed NOT to move most of
-    these bytes; the figure is the yardstick shared with a streaming implementation."""
+    the resolve + 12 accumulated; scenes of the all-triangles intersector are LDS-resident, BVH
+    scenes add 32 per node and 48 per triangle the traversals visit, counted on the device):
+    B_seg = 176 + 64 * N_shadow (+ BVH term), B_path = segments/path * (B_seg + 24) + 12.  The
+    tracer here is designed NOT to move most of these bytes; the figure is the yardstick shared
+    with a streaming implementation."""
     seg_per_path = st["segments"] / max(st["paths"], 1)
     b_seg = 176 + 64 * n_square
-    return st["paths"] * (seg_per_path * (b_seg + 24) + 12)
+    bvh = 32 * st.get("bvh_nodes", 0) + 48 * st.get("bvh_tris", 0)
+    return st["paths"] * (seg_per_path * (b_seg + 24) + 12) + bvh
 
 
 def pmc_calibration(mode):
@@ -220,7 +223,8 @@ def main():
             "mrays_per_s": round((st["segments"] + st["shadow_rays"]) * world * args.steps / dt / 1e6, 1),
             "segments_per_path": round(st["segments"] / st["paths"], 3),
             "roofline": roofline, "valu": valu, "kernels": kernels, "kernel_ms_per_step": kernel_ms,
-            "step_stats": {k: int(ps[k]) for k in ("paths", "segments", "shadow_rays", "records", "wave_iterations", "passes")},
+            "step_stats": {k: int(ps[k]) for k in ("paths", "segments", "shadow_rays", "records", "wave_iterations", "passes",
+                                                   "bvh_nodes", "bvh_tris")},
             "other_mode": {"dtype": other_mode, "value": None if other_value is None else round(other_value, 3),
                            "wave_iterations": int(ost["wave_iterations"]), "passes": int(ost["passes"])},
             "cpu_baseline": cpu, "checks": checks,

@@ -76,6 +76,8 @@ typedef struct ptx_stats
     uint64_t wave_iterations; /* 64-lane bounce iterations of the tracer: segments /
                                (64 * wave_iterations) is its active-lane fraction               */
     uint64_t records;       /* (direct, coefficient) records written = shaded segments           */
+    uint64_t bvh_nodes;     /* BVH node records visited by all rays (0: all-triangles intersector) */
+    uint64_t bvh_tris;      /* BVH triangle records visited (exact tests run by the traversal)   */
     double ms_total;        /* device time of the call, HIP events on the context's stream       */
     double ms_trace, ms_accumulate, ms_other; /* per-kernel device time (profiling
                                mode only, otherwise 0)                                           */

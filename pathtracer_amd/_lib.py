@@ -40,7 +40,7 @@ class RenderOpts(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("shadow_rays", C.c_uint64),
-                ("passes", C.c_uint64), ("wave_iterations", C.c_uint64), ("records", C.c_uint64), ("ms_total", C.c_double), ("ms_trace", C.c_double),
+                ("passes", C.c_uint64), ("wave_iterations", C.c_uint64), ("records", C.c_uint64), ("bvh_nodes", C.c_uint64), ("bvh_tris", C.c_uint64), ("ms_total", C.c_double), ("ms_trace", C.c_double),
                 ("ms_accumulate", C.c_double), ("ms_other", C.c_double)]
 
 

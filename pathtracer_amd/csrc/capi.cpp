@@ -520,6 +520,7 @@ int ptx_render(ptx_context *c, const ptx_render_opts *o, double *rgb_sum, int32_
         stats->passes = st.passes;
         stats->wave_iterations = st.wave_iterations;
         stats->records = st.records;
+        stats->bvh_nodes = st.bvh_nodes, stats->bvh_tris = st.bvh_tris;
         stats->ms_total = st.ms_total;
         stats->ms_trace = st.ms_class[0], stats->ms_accumulate = st.ms_class[2];
         stats->ms_other = st.ms_class[3];

@@ -257,7 +257,7 @@ template <class R> struct Context::Impl
         };
         const size_t o_stack = take(N * 6 * sizeof(R) * depth);
         const size_t o_res = take(N * 3 * sizeof(R));
-        const size_t o_ws = take(static_cast<size_t>(MAX_TRACE_WAVES) * 4 * sizeof(unsigned long long));
+        const size_t o_ws = take(static_cast<size_t>(MAX_TRACE_WAVES) * WAVE_STATS * sizeof(unsigned long long));
         const size_t o_stats = take(sizeof(unsigned long long) * 8);
         const size_t o_pool = take(sizeof(unsigned int));
         state_mem.alloc(total);
@@ -742,6 +742,8 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     stats.paths = h_stats[2];
     stats.wave_iterations = h_stats[3];
     stats.records = h_stats[4];
+    stats.bvh_nodes = h_stats[5];
+    stats.bvh_tris = h_stats[6];
     stats.passes = passes;
     stats.ms_total = ms;
     if (tm)

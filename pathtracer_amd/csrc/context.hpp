@@ -28,7 +28,7 @@ struct RenderOpts
 
 struct RenderStats
 {
-    uint64_t paths = 0, segments = 0, shadow_rays = 0, passes = 0, wave_iterations = 0, records = 0;
+    uint64_t paths = 0, segments = 0, shadow_rays = 0, passes = 0, wave_iterations = 0, records = 0, bvh_nodes = 0, bvh_tris = 0;
     double ms_total = 0;
     double ms_class[4] = {0, 0, 0, 0}; // trace, (unused), accumulate, other
 };

@@ -25,6 +25,7 @@ namespace ptx
 
 constexpr int BLOCK = 256;      // threads per workgroup (4 waves)
 constexpr int BVH_STACK_MAX = 96; // most per-lane traversal stack entries (1 KB of LDS per entry and workgroup)
+constexpr int WAVE_STATS = 6;     // statistics columns per wave
 constexpr int MAX_MATS = 0xFFFE; // the path state word keeps the tail material in 16 bits
 
 template <class R> struct DScene
@@ -84,7 +85,7 @@ template <class R> struct DState
 {
     R *stack;                       // [N][depth][6] by pid: direct rgb, coefficient rgb of every bounce
     R *result;                      // [3][N] by pid: resolved per-sample radiance (written by the tracer)
-    unsigned long long *wave_stats; // [n_waves][4] segments, shadow tests, wave iterations, records
+    unsigned long long *wave_stats; // [n_waves][WAVE_STATS] segments, shadow tests, wave iterations, records, BVH node visits, BVH triangle visits
     unsigned long long *stats;      // [8] totals (filled by k_reduce_stats)
     unsigned int *pool;             // next unassigned path id of the current batch
     int64_t N;                      // capacity (paths per batch)
@@ -264,6 +265,7 @@ template <class R> struct Trav
 {
     int cur;      // record to visit next
     int sp, target, best_face;
+    uint32_t nv, tv; // node / triangle records visited (statistics)
     R best;       // closest accepted distance so far (any-hit: length of the segment)
     V3<R> pt;
     float ohx, ohy, ohz, olx, oly, olz; // upper / lower end of the origin interval
@@ -272,6 +274,7 @@ template <class R> struct Trav
 template <class R> __device__ __forceinline__ void trav_init(Trav<R> &T, V3<R> o, V3<R> d, R limit = Consts<R>::big)
 {
     T.cur = 0, T.sp = 0, T.target = -1, T.best_face = 0x7fffffff;
+    T.nv = T.tv = 0;
     T.best = limit;
     T.pt = {R(0), R(0), R(0)};
     const float fx = float(o.x), fy = float(o.y), fz = float(o.z);
@@ -317,6 +320,7 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
     uint32_t next = 0xFFFFFFFFu;
     if (T.cur >= S.n_nodes)
     {
+        T.tv++;
         R tri[12], t;
         unpack_tri(tri, q0, q1, q2, q3, q4, q5);
         if (tri_test(tri, o, d, t))
@@ -346,6 +350,7 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
     }
     else
     {
+        T.nv++;
         const float tmaxf = float(T.best) * (1.0f + K) + 1e-30f;
         auto slab = [&](uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint32_t hy, uint32_t hz, uint32_t child) {
             const float ax = (__uint_as_float(lx) - T.ohx) * T.ivx, bx = (__uint_as_float(hx) - T.olx) * T.ivx;
@@ -480,7 +485,8 @@ __device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d,
 
 // segment visibility p1 -> p2: blocked iff some triangle has self_eps < t < |p1 - p2| - self_eps
 template <class R, bool BRUTE>
-__device__ __forceinline__ bool visible(const DScene<R> &S, V3<R> p1, V3<R> p2, int *stk, int skip = -1, uint32_t rec_mask = 0xFFFFFFFFu)
+__device__ __forceinline__ bool visible(const DScene<R> &S, V3<R> p1, V3<R> p2, int *stk, int skip = -1, uint32_t rec_mask = 0xFFFFFFFFu,
+                                        uint32_t *visits = nullptr)
 {
     const R self_eps = Consts<R>::self_eps;
     R dist = norm(p1 - p2);
@@ -512,6 +518,8 @@ __device__ __forceinline__ bool visible(const DScene<R> &S, V3<R> p1, V3<R> p2, 
     while (bvh_step<R, true>(S, p1, dir, T, stk))
     {
     }
+    if (visits)
+        visits[0] += T.nv, visits[1] += T.tv;
     return T.target < 0;
 }
 
@@ -714,6 +722,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
     int bounce = 0, prim = -1;
     uint64_t key = 0;
     uint32_t n_seg = 0, n_tests = 0, n_iter = 0, n_rec = 0;
+    uint32_t n_visit[2] = {0, 0}; // BVH node / triangle records visited by this lane
 
     // tests the first n (<= 64) parked segments, one per lane, and removes the direct light of
     // the blocked ones from their bounce records
@@ -929,7 +938,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             if constexpr (BRUTE)
                 hit_k = closest_hit<R, BRUTE>(S, o, d, p, stk, prim);
             else
-                hit_k = T.target, p = T.pt;
+                hit_k = T.target, p = T.pt, n_visit[0] += T.nv, n_visit[1] += T.tv;
             int mat_id = -1;
             if (hit_k >= 0)
                 mat_id = NRM ? lds_tmat[hit_k] : S.tri_mat[hit_k];
@@ -1019,7 +1028,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                         park = true, park_x1 = x1, park_x2 = x2; // the term counts unless the test fails later
                     else if constexpr (LIGHTS == 2)
                     {
-                        if (!visible<R, BRUTE>(S, ro, p, stk, hit_k))
+                        if (!visible<R, BRUTE>(S, ro, p, stk, hit_k, 0xFFFFFFFFu, n_visit))
                             continue;
                     }
                 }
@@ -1087,12 +1096,20 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         n_tests += __shfl_down(n_tests, off, 64);
         n_rec += __shfl_down(n_rec, off, 64);
     }
+    unsigned long long visits0 = n_visit[0], visits1 = n_visit[1];
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        visits0 += __shfl_down(visits0, off, 64);
+        visits1 += __shfl_down(visits1, off, 64);
+    }
     if (lane == 0)
     {
-        st.wave_stats[g * 4 + 0] = n_seg;
-        st.wave_stats[g * 4 + 1] = n_tests;
-        st.wave_stats[g * 4 + 2] = n_iter;
-        st.wave_stats[g * 4 + 3] = n_rec;
+        st.wave_stats[g * WAVE_STATS + 0] = n_seg;
+        st.wave_stats[g * WAVE_STATS + 1] = n_tests;
+        st.wave_stats[g * WAVE_STATS + 2] = n_iter;
+        st.wave_stats[g * WAVE_STATS + 3] = n_rec;
+        st.wave_stats[g * WAVE_STATS + 4] = visits0;
+        st.wave_stats[g * WAVE_STATS + 5] = visits1;
     }
 }
 
@@ -1134,18 +1151,18 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_accumulate(DBatch 
 // sums the per-wave statistics of a batch into the totals (single workgroup, no atomics)
 template <class R> __global__ void __launch_bounds__(BLOCK) k_reduce_stats(DBatch B, DState<R> st)
 {
-    __shared__ unsigned long long part[4][BLOCK];
-    unsigned long long a[4] = {0, 0, 0, 0};
+    __shared__ unsigned long long part[WAVE_STATS][BLOCK];
+    unsigned long long a[WAVE_STATS] = {0};
     for (int g = threadIdx.x; g < st.n_waves; g += BLOCK)
-        for (int c = 0; c < 4; c++)
-            a[c] += st.wave_stats[g * 4 + c];
-    for (int c = 0; c < 4; c++)
+        for (int c = 0; c < WAVE_STATS; c++)
+            a[c] += st.wave_stats[g * WAVE_STATS + c];
+    for (int c = 0; c < WAVE_STATS; c++)
         part[c][threadIdx.x] = a[c];
     __syncthreads();
     for (int w = BLOCK / 2; w > 0; w >>= 1)
     {
         if (int(threadIdx.x) < w)
-            for (int c = 0; c < 4; c++)
+            for (int c = 0; c < WAVE_STATS; c++)
                 part[c][threadIdx.x] += part[c][threadIdx.x + w];
         __syncthreads();
     }
@@ -1156,6 +1173,8 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_reduce_stats(DBatc
         st.stats[2] += (unsigned long long)B.n_paths;
         st.stats[3] += part[2][0]; // wave iterations of k_trace (64 lanes each)
         st.stats[4] += part[3][0]; // stack records written (shaded segments)
+        st.stats[5] += part[4][0]; // BVH node records visited
+        st.stats[6] += part[5][0]; // BVH triangle records visited
         *st.pool = 0u;             // the next batch starts from path id 0
     }
 }

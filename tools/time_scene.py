@@ -23,3 +23,6 @@ util = st["segments"] / (64.0 * max(st["wave_iterations"], 1))
 print("%s %dx%d %d spp %s: %.1f Mpaths/s (%.1f ms), %.2f segments/path, %.2f shadow rays/path, lane util %.3f" % (
     conf, W, W, spp, mode, st["paths"] / st["ms_total"] / 1e3, st["ms_total"], st["segments"] / st["paths"],
     st["shadow_rays"] / st["paths"], util), flush=True)
+if st["bvh_nodes"]:
+    rays = st["segments"] + st["shadow_rays"]
+    print("BVH records visited per ray: %.2f nodes, %.2f triangles" % (st["bvh_nodes"] / rays, st["bvh_tris"] / rays), flush=True)
