@@ -81,6 +81,7 @@ template <class R> struct Context::Impl
 {
     DeviceBuffer tri_pre, mats, lights, tri_nrm;
     DeviceBuffer bvh; // 4-wide BVH records (nodes, then the triangles of tri_pre)
+    DeviceBuffer spill; // traversal stack levels beyond the LDS ones, [level][lane of the launch]
     DeviceBuffer state_mem; // one slab carved into the DState arrays
     DState<R> st;
     int64_t capacity = 0;
@@ -281,6 +282,7 @@ struct Context::Geometry
     int n_recs = 0;
     float smax = 0.f;
     int n_nodes = 0, id_bits = 1; // 4-wide BVH: node records, bits of the record id in a stack entry
+    int stack_need = 1;           // stack entries a traversal can need
 };
 
 Context::Context(int device) : device_(device)
@@ -380,6 +382,7 @@ void Context::build_accel(const Scene &sc)
     geo_->n_recs = pr.n_recs;
     geo_->n_nodes = static_cast<int>(bvh_.nodes.size());
     geo_->id_bits = id_bits_;
+    geo_->stack_need = std::max(bvh_.stack_need, 1);
     geo_->smax = pr.smax;
     f64_->build_tables(sc, bvh_, brute_, s);
     f32_->build_tables(sc, bvh_, brute_, s);
@@ -416,7 +419,9 @@ template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::
     S.tri_mat = static_cast<const int32_t *>(g.tri_mat.p);
     S.bvh = static_cast<const uint4 *>(bvh);
     S.n_nodes = g.n_nodes, S.id_bits = g.id_bits;
-    S.pad2_[0] = S.pad2_[1] = 0;
+    S.stack_levels = g.stack_need; // the operator kernels keep the whole stack in LDS
+    S.spill_stride = 0;
+    S.spill = nullptr;
     return S;
 }
 
@@ -542,12 +547,13 @@ template <class R> struct TracePlan
     void (*kernel)(DScene<R>, DCamera, DBatch, DState<R>, int) = nullptr;
     int blocks_per_cu = 1;
     size_t dyn_lds = 0; // bytes of traversal stacks per workgroup (BVH kernels)
+    int stack_levels = 0; // levels of them
 };
 
-template <class R, bool BRUTE> static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shadow_queue, size_t dyn_lds)
+template <class R, bool BRUTE>
+static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shadow_queue, int stack_need, int lds_stack_min)
 {
     TracePlan<R> p;
-    p.dyn_lds = dyn_lds;
     const bool tab = S.n_mats <= LDS_MATS && S.n_lights <= LDS_LIGHTS;
     // how visibility tests are compiled (see trace_body): none / parked in the LDS queue / in place
     const int lights = S.n_square == 0 ? 0 : ((BRUTE && S.n_lights == 1 && shadow_queue) ? 1 : 2);
@@ -572,12 +578,51 @@ template <class R, bool BRUTE> static TracePlan<R> plan_trace(const DScene<R> &S
         pick(std::true_type());
     else
         pick(std::false_type());
-    allow_dynamic_lds(p.kernel, dyn_lds);
+    // BVH kernels: how many stack levels to keep in LDS.  The registers (and the static LDS)
+    // allow `by_regs` workgroups per CU; the stacks get what is left of the CU's LDS at that
+    // occupancy, as long as that is a useful depth, and deeper levels spill to global memory.
     int per_cu = blocks_per_cu;
-    if (per_cu <= 0)
-        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, p.kernel, BLOCK, dyn_lds));
+    p.stack_levels = 0;
+    if (!BRUTE)
+    {
+        hipFuncAttributes fa;
+        HIP_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(p.kernel)));
+        int dev = 0, lds_cu = 0, by_regs = 1;
+        HIP_CHECK(hipGetDevice(&dev));
+        HIP_CHECK(hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev));
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&by_regs, p.kernel, BLOCK, 0));
+        if (per_cu > 0)
+            by_regs = std::min(by_regs, per_cu);
+        const int useful = std::min(stack_need, lds_stack_min);
+        int levels = stack_need;
+        per_cu = 1;
+        for (int b = std::max(by_regs, 1); b >= 1; b--)
+        {
+            const int avail = lds_cu / b - static_cast<int>(fa.sharedSizeBytes);
+            int lv = std::min(stack_need, avail / (BLOCK * 4));
+            int got = 0;
+            while (lv >= useful)
+            {
+                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, p.kernel, BLOCK, static_cast<size_t>(lv) * BLOCK * 4));
+                if (got >= b)
+                    break;
+                lv--; // allocation granularity
+            }
+            if (lv >= useful && got >= b)
+            {
+                levels = lv, per_cu = b;
+                break;
+            }
+        }
+        p.stack_levels = levels;
+        p.dyn_lds = static_cast<size_t>(levels) * BLOCK * 4;
+        allow_dynamic_lds(p.kernel, p.dyn_lds);
+    }
+    else if (per_cu <= 0)
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, p.kernel, BLOCK, 0));
     if (std::getenv("PTX_DEBUG"))
-        std::fprintf(stderr, "[ptx] trace kernel: %d workgroups per CU, %zu bytes of dynamic LDS\n", per_cu, dyn_lds);
+        std::fprintf(stderr, "[ptx] trace kernel: %d workgroups per CU, %zu bytes of dynamic LDS (%d of %d stack levels)\n", per_cu,
+                     p.dyn_lds, p.stack_levels, stack_need);
     p.blocks_per_cu = std::max(per_cu, 1);
     return p;
 }
@@ -699,7 +744,23 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     DCamera cam = make_camera(sc);
     RenderTimers *tm = o.profile ? &timers_ : nullptr;
     // The grid of the tracer is just large enough to fill the device: its waves are persistent.
-    const TracePlan<R> plan = brute_ ? plan_trace<R, true>(S, trace_blocks_per_cu, shadow_queue, 0) : plan_trace<R, false>(S, trace_blocks_per_cu, shadow_queue, stack_bytes());
+    const TracePlan<R> plan = brute_ ? plan_trace<R, true>(S, trace_blocks_per_cu, shadow_queue, 0, 0)
+                                    : plan_trace<R, false>(S, trace_blocks_per_cu, shadow_queue, geo_->stack_need, lds_stack_levels);
+    if (!brute_)
+    {
+        // stack levels the LDS does not hold: one column per lane of the launch in global memory
+        S.stack_levels = plan.stack_levels;
+        const int over = geo_->stack_need - plan.stack_levels;
+        if (over > 0)
+        {
+            const int64_t lanes = std::min<int64_t>(static_cast<int64_t>(plan.blocks_per_cu) * n_cus_, MAX_TRACE_WAVES / (BLOCK / 64)) * BLOCK;
+            const size_t bytes = static_cast<size_t>(lanes) * over * sizeof(uint32_t);
+            if (im.spill.bytes < bytes)
+                im.spill.alloc(bytes);
+            S.spill = static_cast<uint32_t *>(im.spill.p);
+            S.spill_stride = static_cast<int>(lanes);
+        }
+    }
 
     hipEvent_t ev0, ev1;
     HIP_CHECK(hipEventCreate(&ev0));

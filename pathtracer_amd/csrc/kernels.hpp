@@ -47,7 +47,10 @@ template <class R> struct DScene
     const R *tri_nrm;          // [n_tris][4] intersector order: shading normal + flag (1: use it; 0: interpolate)
     const int32_t *tri_mat;    // [n_tris] intersector order: material id (-1: none)
     const uint4 *bvh;          // [n_nodes + n_tris][8] 4-wide BVH records: nodes, then triangles in intersector order
-    int n_nodes, id_bits, pad2_[2]; // id_bits: bits of a stack entry that hold the record id
+    int n_nodes, id_bits;      // id_bits: bits of a stack entry that hold the record id
+    int stack_levels;          // traversal stack levels held in LDS; deeper levels go to `spill`
+    int spill_stride;          // lanes of the launch
+    uint32_t *spill;           // [levels beyond stack_levels][spill_stride] (null when the LDS stack holds the whole bound)
 };
 
 struct DCamera
@@ -265,18 +268,16 @@ template <class R> struct Trav
 {
     int cur;      // record to visit next
     int sp, target, best_face;
-    uint32_t nv, tv; // node / triangle records visited (statistics)
     R best;       // closest accepted distance so far (any-hit: length of the segment)
-    V3<R> pt;
+    R best_t;     // ray parameter of that hit: the hit point is o + best_t * d
     float ohx, ohy, ohz, olx, oly, olz; // upper / lower end of the origin interval
     float ivx, ivy, ivz;                // 1 / d, finite
 };
 template <class R> __device__ __forceinline__ void trav_init(Trav<R> &T, V3<R> o, V3<R> d, R limit = Consts<R>::big)
 {
     T.cur = 0, T.sp = 0, T.target = -1, T.best_face = 0x7fffffff;
-    T.nv = T.tv = 0;
     T.best = limit;
-    T.pt = {R(0), R(0), R(0)};
+    T.best_t = R(0);
     const float fx = float(o.x), fy = float(o.y), fz = float(o.z);
     const float P = 0x1p-22f * fmaxf(fmaxf(fabsf(fx), fabsf(fy)), fabsf(fz)) + 1e-30f;
     T.ohx = fx + P, T.ohy = fy + P, T.ohz = fz + P;
@@ -305,12 +306,19 @@ __device__ __forceinline__ void unpack_tri(float *tri, const uint4 &q0, const ui
     tri[8] = __uint_as_float(q2.x), tri[9] = __uint_as_float(q2.y), tri[10] = __uint_as_float(q2.z), tri[11] = __uint_as_float(q2.w);
 }
 
+// The two homes of a stack level, addressed through explicit address spaces: left generic, the
+// compiler merges the two stores of a push into one flat store behind a pointer select.
+typedef __attribute__((address_space(3))) int lds_int_t;
+typedef __attribute__((address_space(1))) uint32_t global_u32_t;
+
 // One record visit.  ANY = false: closest hit (winner = smallest distance beyond self_eps, ties ->
-// lowest face id; T.target = triangle, T.pt = point).  ANY = true: is the segment of length T.best
+// lowest face id; T.target = triangle, o + T.best_t * d = point).  ANY = true: is the segment of length T.best
 // blocked (T.target = 1 and the traversal ends at the first blocker).  The lane's stack is
 // stk[level * BLOCK] in LDS.  Returns false once the traversal is complete.
-template <class R, bool ANY>
-__device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, Trav<R> &T, int *stk)
+// KIND = 1 / 2: the caller has established that the lane is at a node / a triangle record (the
+// tracer advances the two kinds in separate wave steps so that neither runs on half-empty lanes).
+template <class R, bool ANY, int KIND = 0>
+__device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, Trav<R> &T, int *stk, uint32_t *visits)
 {
     constexpr float K = 0x1p-20f;
     const R self_eps = Consts<R>::self_eps;
@@ -318,9 +326,9 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
     const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
     const int id_bits = S.id_bits;
     uint32_t next = 0xFFFFFFFFu;
-    if (T.cur >= S.n_nodes)
+    if (KIND == 2 || (KIND == 0 && T.cur >= S.n_nodes))
     {
-        T.tv++;
+        visits[1]++;
         R tri[12], t;
         unpack_tri(tri, q0, q1, q2, q3, q4, q5);
         if (tri_test(tri, o, d, t))
@@ -343,14 +351,14 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
                     T.best = dist;
                     T.best_face = face;
                     T.target = T.cur - S.n_nodes;
-                    T.pt = p;
+                    T.best_t = t;
                 }
             }
         }
     }
     else
     {
-        T.nv++;
+        visits[0]++;
         const float tmaxf = float(T.best) * (1.0f + K) + 1e-30f;
         auto slab = [&](uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint32_t hy, uint32_t hz, uint32_t child) {
             const float ax = (__uint_as_float(lx) - T.ohx) * T.ivx, bx = (__uint_as_float(hx) - T.olx) * T.ivx;
@@ -371,15 +379,38 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
             a = lo, b = hi;
         };
         order(k0, k1), order(k2, k3), order(k0, k2), order(k1, k3), order(k1, k2);
-        // nearest child next, the others on the stack, farthest first (the host has checked that
-        // the tree cannot overflow the stack)
+        // nearest child next, the others on the stack, farthest first.  The first S.stack_levels
+        // levels live in LDS; the host sizes them so that deeper ones (a global array the lane
+        // owns a column of) are the exception, and has checked the tree against the total
         if (k1 != 0xFFFFFFFFu)
         {
-            if (k3 != 0xFFFFFFFFu)
-                stk[(T.sp++) * BLOCK] = int(k3);
-            if (k2 != 0xFFFFFFFFu)
-                stk[(T.sp++) * BLOCK] = int(k2);
-            stk[(T.sp++) * BLOCK] = int(k1);
+            if (T.sp + 3 <= S.stack_levels)
+            {
+                // the usual case: all of it fits the LDS levels
+                lds_int_t *top = (lds_int_t *)(stk + T.sp * BLOCK);
+                int n = 0;
+                if (k3 != 0xFFFFFFFFu)
+                    top[(n++) * BLOCK] = int(k3);
+                if (k2 != 0xFFFFFFFFu)
+                    top[(n++) * BLOCK] = int(k2);
+                top[(n++) * BLOCK] = int(k1);
+                T.sp += n;
+            }
+            else
+            {
+                auto push = [&](uint32_t e) {
+                    if (T.sp < S.stack_levels)
+                        *(lds_int_t *)(stk + T.sp * BLOCK) = int(e);
+                    else
+                        *(global_u32_t *)(S.spill + (uint32_t(T.sp - S.stack_levels) * uint32_t(S.spill_stride) + (blockIdx.x * BLOCK + threadIdx.x))) = e;
+                    T.sp++;
+                };
+                if (k3 != 0xFFFFFFFFu)
+                    push(k3);
+                if (k2 != 0xFFFFFFFFu)
+                    push(k2);
+                push(k1);
+            }
         }
         next = k0;
     }
@@ -392,7 +423,12 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
     const float tmaxf = float(T.best) * (1.0f + K) + 1e-30f;
     while (T.sp > 0)
     {
-        const uint32_t e = uint32_t(stk[(--T.sp) * BLOCK]);
+        --T.sp;
+        uint32_t e;
+        if (T.sp < S.stack_levels)
+            e = uint32_t(*(lds_int_t *)(stk + T.sp * BLOCK));
+        else
+            e = *(global_u32_t *)(S.spill + (uint32_t(T.sp - S.stack_levels) * uint32_t(S.spill_stride) + (blockIdx.x * BLOCK + threadIdx.x)));
         if (__uint_as_float((e >> id_bits) << (id_bits - 1)) <= tmaxf)
         {
             T.cur = int(e & id_mask);
@@ -475,11 +511,12 @@ __device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d,
         return target;
     }
     Trav<R> T;
+    uint32_t visits[2] = {0, 0};
     trav_init(T, o, d);
-    while (bvh_step<R, false>(S, o, d, T, stk))
+    while (bvh_step<R, false>(S, o, d, T, stk, visits))
     {
     }
-    pt = T.pt;
+    pt = o + T.best_t * d;
     return T.target;
 }
 
@@ -515,11 +552,10 @@ __device__ __forceinline__ bool visible(const DScene<R> &S, V3<R> p1, V3<R> p2, 
     }
     Trav<R> T;
     trav_init(T, p1, dir, dist);
-    while (bvh_step<R, true>(S, p1, dir, T, stk))
+    uint32_t none[2] = {0, 0};
+    while (bvh_step<R, true>(S, p1, dir, T, stk, visits ? visits : none))
     {
     }
-    if (visits)
-        visits[0] += T.nv, visits[1] += T.tv;
     return T.target < 0;
 }
 
@@ -865,8 +901,18 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 const int n_serve = __popcll(__ballot(alive && trav_done)) + (can_start ? __popcll(__ballot(!alive)) : 0);
                 if (n_serve >= 32 || (n_serve > 0 && n_trav <= n_serve))
                     break;
-                if (alive && !trav_done)
-                    trav_done = !bvh_step<R, false>(S, o, d, T, stk);
+                // nodes and triangles in separate wave steps (f32 slab tests / exact test in R), the
+                // kind that serves more lanes per cycle first
+                const bool act = alive && !trav_done;
+                const bool at_tri = act && T.cur >= S.n_nodes;
+                const int n_tri = __popcll(__ballot(at_tri));
+                if (n_tri * 2 > (n_trav - n_tri) * 3)
+                {
+                    if (at_tri)
+                        trav_done = !bvh_step<R, false, 2>(S, o, d, T, stk, n_visit);
+                }
+                else if (act && !at_tri)
+                    trav_done = !bvh_step<R, false, 1>(S, o, d, T, stk, n_visit);
             }
         }
         // ---- idle lanes start the next paths ------------------------------------------------------
@@ -938,7 +984,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             if constexpr (BRUTE)
                 hit_k = closest_hit<R, BRUTE>(S, o, d, p, stk, prim);
             else
-                hit_k = T.target, p = T.pt, n_visit[0] += T.nv, n_visit[1] += T.tv;
+                hit_k = T.target, p = o + T.best_t * d;
             int mat_id = -1;
             if (hit_k >= 0)
                 mat_id = NRM ? lds_tmat[hit_k] : S.tri_mat[hit_k];
