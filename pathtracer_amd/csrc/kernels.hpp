@@ -1032,15 +1032,6 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 nrm = fast_normalized(acc);
             }
 
-            // ---- next direction and indirect coefficient -----------------------------------------
-            V3<R> coef = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
-            if (S.enable_indirect)
-            {
-                const R x1 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 0);
-                const R x2 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 1);
-                bxdf_sample(m, nrm, wo, x1, x2, wi, coef);
-            }
-
             // ---- NEE over all lights, in order; a square-light sample needs a visibility test ----
             V3<R> direct = {R(0), R(0), R(0)};
             for (int l = 0; l < S.n_lights; l++)
@@ -1054,7 +1045,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 R pdf;
                 const R x1 = rng_draw<R>(key, sample, bounce, 4 * l + 0);
                 const R x2 = rng_draw<R>(key, sample, bounce, 4 * l + 1);
-                const bool square = SQ1 || L[0] == R(0);
+                const bool square = SQ1 || (LIGHTS != 0 && L[0] == R(0)); // LIGHTS == 0: the scene has no square light
                 if (square)
                     pdf = square_light_sample(L, p, x1, x2, ro, rd);
                 else
@@ -1079,6 +1070,15 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                     }
                 }
                 direct = direct + term;
+            }
+
+            // ---- next direction and indirect coefficient (after the light loop: fewer values live in it) --
+            V3<R> coef = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
+            if (S.enable_indirect)
+            {
+                const R x1 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 0);
+                const R x2 = rng_draw<R>(key, sample, bounce, 4 * S.n_lights + 1);
+                bxdf_sample(m, nrm, wo, x1, x2, wi, coef);
             }
 
             // ---- one stack record per shaded segment -------------------------------------------------
