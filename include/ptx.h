@@ -141,8 +141,10 @@ void ptx_context_destroy(ptx_context *);
  * tracer launch; default 2^26), "chunk_paths" (path ids a wave of the tracer takes from the pool at
  * a time, 64..65536), "trace_blocks_per_cu" (workgroups of the tracer per compute unit; 0 = what
  * the occupancy calculator reports), "shadow_queue" (1/0: park the visibility tests of
- * one-square-light scenes in the per-wave LDS queue, or run them in place).  Results do not depend
- * on any of them.  Set before ptx_build_accel. */
+ * one-square-light scenes in the per-wave LDS queue, or run them in place), "lds_stack_levels"
+ * (BVH scenes: at most this many traversal stack levels per lane in LDS, deeper ones in a global
+ * array; 0 = as many as fit at full occupancy).  Results do not depend on any of them.  Set before
+ * ptx_build_accel. */
 int ptx_context_set_option(ptx_context *, const char *name, int64_t value);
 int ptx_build_accel(ptx_context *, const ptx_scene *);
 /* BVH statistics of the last build: n_nodes (4-wide), n_leaves (= triangles), max_depth, stack_need (most

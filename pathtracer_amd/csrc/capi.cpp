@@ -413,7 +413,7 @@ int ptx_context_set_option(ptx_context *c, const char *name, int64_t value)
         c->ctx->brute_force_limit = static_cast<int>(value);
     else if (n == "default_batch_paths" && value > 0)
         c->ctx->default_batch_paths = value;
-    else if (n == "lds_stack_levels" && value >= 1 && value <= 96)
+    else if (n == "lds_stack_levels" && value >= 0 && value <= 96)
         c->ctx->lds_stack_levels = static_cast<int>(value);
     else if (n == "shadow_queue" && (value == 0 || value == 1))
         c->ctx->shadow_queue = value != 0;

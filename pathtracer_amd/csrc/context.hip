@@ -551,7 +551,7 @@ template <class R> struct TracePlan
 };
 
 template <class R, bool BRUTE>
-static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shadow_queue, int stack_need, int lds_stack_min)
+static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shadow_queue, int stack_need, int lds_stack_cap)
 {
     TracePlan<R> p;
     const bool tab = S.n_mats <= LDS_MATS && S.n_lights <= LDS_LIGHTS;
@@ -593,13 +593,16 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&by_regs, p.kernel, BLOCK, 0));
         if (per_cu > 0)
             by_regs = std::min(by_regs, per_cu);
-        const int useful = std::min(stack_need, lds_stack_min);
-        int levels = stack_need;
+        // below about 24 levels in LDS the spills stop being the exception; lds_stack_cap (an
+        // option for tests and tuning) forces a smaller LDS stack
+        const int cap = lds_stack_cap > 0 ? std::min(lds_stack_cap, stack_need) : stack_need;
+        const int useful = std::min(cap, 24);
+        int levels = cap;
         per_cu = 1;
         for (int b = std::max(by_regs, 1); b >= 1; b--)
         {
             const int avail = lds_cu / b - static_cast<int>(fa.sharedSizeBytes);
-            int lv = std::min(stack_need, avail / (BLOCK * 4));
+            int lv = std::min(cap, avail / (BLOCK * 4));
             int got = 0;
             while (lv >= useful)
             {

@@ -84,7 +84,9 @@ public:
     int trace_blocks_per_cu = 0;
     // single-square-light scenes: park visibility tests in a per-wave LDS queue (full-wave tests)
     bool shadow_queue = true;
-    int lds_stack_levels = 24; // BVH tracer: keep at least this many traversal stack levels in LDS (deeper ones spill)
+    // BVH tracer: at most this many traversal stack levels in LDS, deeper ones spill to global memory
+    // (0: as many as fit at full occupancy)
+    int lds_stack_levels = 0;
 
     struct Geometry;
     template <class R> struct Impl;

@@ -233,6 +233,33 @@ def test_tracer_scheduling_options_are_bit_invariant(root):
     assert np.array_equal(c.render(mode="f32")[0], b32)
 
 
+@pytest.mark.parametrize("conf,kw", [("config/mis.conf", dict(width=96, height=64, spp=4)),
+                                     ("config/cbox.conf", dict(width=64, height=64, spp=4))])
+def test_bvh_stack_spill_is_bit_invariant(root, conf, kw):
+    """BVH traversal stacks: however few levels are kept in LDS (deeper ones go to a global column
+    per lane), closest hits and visibility tests are the same to the bit, in both precisions."""
+    s, ref = load(root, conf, **kw)
+    imgs = {}
+    for levels in (0, 1, 3, 8):
+        c = pt.Context(0, brute_force_limit=0)                      # the BVH also on the Cornell box
+        c.set_option("lds_stack_levels", levels)
+        c.build_accel(s)
+        assert not c.accel_info()["brute_force"]
+        for mode in ("f64", "f32"):
+            img, st = c.render(mode=mode)
+            key = (mode,)
+            if key in imgs:
+                assert np.array_equal(img, imgs[key][0]), (levels, mode)
+                assert st["bvh_nodes"] == imgs[key][1]["bvh_nodes"] and st["bvh_tris"] == imgs[key][1]["bvh_tris"]
+            else:
+                imgs[key] = (img, st)
+                assert st["bvh_nodes"] > 0 and st["bvh_tris"] > 0
+    # and the all-triangles intersector agrees with all of them on the Cornell box
+    if conf.endswith("cbox.conf"):
+        base, _ = make_ctx(s).render(mode="f64")
+        assert np.array_equal(base, imgs[("f64",)][0])
+
+
 def test_render_f32_meets_rmse_bar(root):
     s, ref = load(root, "config/cbox.conf", width=64, height=64, spp=16)
     c = make_ctx(s)
