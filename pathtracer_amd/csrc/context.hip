@@ -152,6 +152,7 @@ template <class R> struct Context::Impl
             o[12] = (std::fabs(src.Ni - 1.0) < 1e-5) ? R(0) : R(1);              // BSDF when Ni != 1
             double ka = std::sqrt(src.Ka[0] * src.Ka[0] + src.Ka[1] * src.Ka[1] + src.Ka[2] * src.Ka[2]);
             o[13] = ka > 1e-6 ? R(1) : R(0);                                     // emitter
+            o[14] = (src.Ns >= 0 && src.Ns <= 1048576.0 && std::floor(src.Ns) == src.Ns && double(R(src.Ns)) == src.Ns) ? R(1) : R(0); // whole-number Ns
         }
         upload(mats, m, s);
 
