@@ -52,6 +52,14 @@ def pmc_sums(path):
 
 
 def short(name):
+    if name.startswith("_Z"):  # some rocprofv3 runs record mangled names (with a ".kd" suffix)
+        import subprocess
+        try:
+            name = subprocess.run(["c++filt", name[:-3] if name.endswith(".kd") else name], capture_output=True, text=True).stdout.strip() or name
+        except OSError:
+            pass
+    elif name.endswith(".kd"):
+        name = name[:-3]
     return name.split("(")[0].replace("void ", "")
 
 
