@@ -1,0 +1,420 @@
+// Tracer of BVH scenes without square lights (no visibility tests): a wave keeps more paths in
+// flight than it has lanes.  Included by kernels.hpp.
+//
+// With the BVH, the 64 lanes of a wave are at three different kinds of work -- node tests, exact
+// triangle tests, shading -- and whatever runs, runs on the lanes that happen to be there.  Here the
+// lanes only traverse.  A lane whose traversal is complete hands the hit (point, direction,
+// triangle, path id, bounce, RNG key) to the wave's HIT RING and takes its next ray from the wave's
+// RAY RING; when 64 hits are waiting, the whole wave shades them, one per lane, and the
+// continuation rays go to the ray ring; camera rays enter through the same ring, 64 at a time.
+// Both rings live in global memory (a wave-private region, written and read with consecutive
+// entries per lane, i.e. coalesced, and by this wave only) because the LDS belongs to the traversal
+// stacks; their traffic, about 130 B (f32) to 270 B (f64) per segment, is small next to the BVH
+// records a segment fetches.  Shading runs on full waves, the traversal steps on the lanes that are
+// not between two rays; every path is in exactly one place (a lane, the ray ring or the hit ring),
+// camera rays are only admitted while fewer than 128 paths are in flight, so neither ring
+// (256 entries) can overflow, and the wave ends when the pool is used up and all three are empty.
+#pragma once
+
+namespace ptx
+{
+
+constexpr int RING_CAP = 256;       // entries of either ring
+constexpr int RING_ADMIT = 128;     // camera rays are admitted while at most this many paths are in flight
+constexpr int RING_BATCH = 16;      // lanes that hand over hits / take rays together
+
+// bytes of one wave's two rings
+template <class R> constexpr size_t ring_bytes() { return size_t(RING_CAP) * (12 * sizeof(R) + 4 * 9); }
+
+// views of the two rings of one wave (structure of arrays: one field of 256 entries after the other)
+template <class R> struct Rings
+{
+    // ray ring
+    R *ro, *rd;        // [3][CAP] each
+    uint32_t *r_pid, *r_bounce, *r_klo, *r_khi;
+    // hit ring
+    R *hp, *hd;        // [3][CAP]: hit point, ray direction
+    int32_t *h_tri;
+    uint32_t *h_pid, *h_bounce, *h_klo, *h_khi;
+    __device__ explicit Rings(void *base)
+    {
+        R *f = reinterpret_cast<R *>(base);
+        ro = f, rd = f + 3 * RING_CAP, hp = f + 6 * RING_CAP, hd = f + 9 * RING_CAP;
+        uint32_t *u = reinterpret_cast<uint32_t *>(f + 12 * RING_CAP);
+        r_pid = u, r_bounce = u + RING_CAP, r_klo = u + 2 * RING_CAP, r_khi = u + 3 * RING_CAP;
+        h_tri = reinterpret_cast<int32_t *>(u + 4 * RING_CAP);
+        h_pid = u + 5 * RING_CAP, h_bounce = u + 6 * RING_CAP, h_klo = u + 7 * RING_CAP, h_khi = u + 8 * RING_CAP;
+    }
+};
+
+// entries written by some lanes of the wave are read by others: wait for the stores (the compute
+// unit's vector cache is coherent for its own waves)
+__device__ __forceinline__ void ring_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// rank of this lane among the set bits of `mask`
+__device__ __forceinline__ uint32_t rank_in(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+}
+
+template <class R, bool TAB>
+__device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCamera &cam, const DBatch &B, const DState<R> &st, int chunk)
+{
+    __shared__ R lds_mats[TAB ? LDS_MATS * MAT_STRIDE : 1];
+    __shared__ R lds_lights[TAB ? LDS_LIGHTS * LIGHT_STRIDE : 1];
+    __shared__ DoneQueue done_queues[BLOCK / 64];
+    if (TAB)
+    {
+        for (int k = threadIdx.x; k < S.n_mats * MAT_STRIDE; k += BLOCK)
+            lds_mats[k] = S.mats[k];
+        for (int k = threadIdx.x; k < S.n_lights * LIGHT_STRIDE; k += BLOCK)
+            lds_lights[k] = S.lights[k];
+    }
+    int *stk = dyn_stack + threadIdx.x;
+    __syncthreads(); // the only barrier: from here on the waves of the workgroup are independent
+    const int g = global_wave(), lane = lane_id();
+    if (g >= st.n_waves)
+        return;
+    const Rings<R> Q(st.rings + size_t(g) * ring_bytes<R>());
+    const uint32_t n_paths = uint32_t(B.n_paths);
+    uint32_t next = 0, end = 0; // the wave's current range of path ids
+    bool drained = false;       // the pool has no ids left (wave-uniform)
+    const uint32_t n_pix = uint32_t(B.n_pix), n_cols = uint32_t(B.n_cols);
+    const int depth = B.depth;
+    const V3<R> cam_pos = {R(cam.pos[0]), R(cam.pos[1]), R(cam.pos[2])};
+    DoneQueue &dq = done_queues[threadIdx.x >> 6];
+    uint32_t dq_head = 0, dq_count = 0;               // wave-uniform
+    uint32_t rq_head = 0, rq_count = 0, hq_head = 0, hq_count = 0; // wave-uniform
+
+    // the ray this lane is traversing
+    bool busy = false, done = false; // done: traversal complete, the hit waits to be handed over
+    Trav<R> T;
+    trav_init(T, V3<R>{R(0), R(0), R(0)}, V3<R>{R(1), R(1), R(1)});
+    V3<R> o = {R(0), R(0), R(0)}, d = {R(0), R(0), R(0)};
+    uint32_t pid = 0, bounce = 0, klo = 0, khi = 0;
+    uint32_t n_seg = 0, n_iter = 0, n_rec = 0;
+    uint32_t n_visit[2] = {0, 0};
+
+    // folds 64 (or the last n) finished paths back to front, one per lane
+    auto resolve = [&](uint32_t n) {
+#pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
+        ring_sync(); // the records were stored by other lanes of this wave
+        const uint32_t e = (dq_head + uint32_t(lane)) % DoneQueue::CAP;
+        const bool mine = uint32_t(lane) < n;
+        const uint32_t rp = mine ? dq.pid[e] : 0u, rs = mine ? dq.state[e] : 0u;
+        const int len = int(rs >> 16), tm = int(rs & 0xffffu);
+        R fr = R(0), fg = R(0), fb = R(0);
+        if (tm)
+        {
+            const R *tmat;
+            if constexpr (TAB)
+                tmat = lds_mats + (tm - 1) * MAT_STRIDE;
+            else
+                tmat = S.mats + (size_t)(tm - 1) * MAT_STRIDE;
+            fr = tmat[0], fg = tmat[1], fb = tmat[2];
+        }
+        int wlen = len;
+        for (int off = 32; off > 0; off >>= 1)
+            wlen = max(wlen, __shfl_xor(wlen, off, 64));
+        const R *rec = st.stack + (size_t)rp * depth * 6;
+        constexpr int G = 2; // levels whose loads are in flight together
+        for (int top = wlen - 1; top >= 0; top -= G)
+        {
+            R q[G][6];
+#pragma unroll
+            for (int k = 0; k < G; k++)
+            {
+                const int i = top - k;
+                const bool on = i >= 0 && i < len;
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+                    q[k][c] = on ? rec[(on ? i : 0) * 6 + c] : R(0);
+            }
+#pragma unroll
+            for (int k = 0; k < G; k++)
+            {
+                const int i = top - k;
+                if (i >= 0 && i < len)
+                {
+                    fr = q[k][0] + q[k][3] * fr;
+                    fg = q[k][1] + q[k][4] * fg;
+                    fb = q[k][2] + q[k][5] * fb;
+                    R mx = fr;
+                    if (fg > mx)
+                        mx = fg;
+                    if (fb > mx)
+                        mx = fb;
+                    if (R(0) > mx)
+                        mx = R(0);
+                    if (mx > R(1))
+                    {
+                        const R inv = R(1) / mx;
+                        fr *= inv, fg *= inv, fb *= inv;
+                    }
+                }
+            }
+        }
+        if (mine)
+            st.result[rp] = fr, st.result[st.N + rp] = fg, st.result[2 * st.N + rp] = fb;
+        dq_head = (dq_head + n) % DoneQueue::CAP;
+        dq_count -= n;
+    };
+
+    // shades the first n (<= 64) hits of the hit ring, one per lane
+    auto shade = [&](uint32_t n) {
+        ring_sync();
+        n_iter++;
+        const uint32_t e = (hq_head + uint32_t(lane)) % RING_CAP;
+        const bool mine = uint32_t(lane) < n;
+        bool finished = false, cont = false;
+        uint32_t fin_state = 0;
+        V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
+        uint32_t s_pid = 0, s_bounce = 0, s_klo = 0, s_khi = 0;
+        if (mine)
+        {
+            n_seg++;
+            p = {Q.hp[e], Q.hp[RING_CAP + e], Q.hp[2 * RING_CAP + e]};
+            const V3<R> sd = {Q.hd[e], Q.hd[RING_CAP + e], Q.hd[2 * RING_CAP + e]};
+            const int hit_k = Q.h_tri[e];
+            s_pid = Q.h_pid[e], s_bounce = Q.h_bounce[e], s_klo = Q.h_klo[e], s_khi = Q.h_khi[e];
+            const uint64_t key = (uint64_t(s_khi) << 32) | s_klo;
+            const uint32_t sample = uint32_t(B.sample0) + s_pid / n_pix;
+            const int bnc = int(s_bounce);
+            // ---- termination rules (miss / no material -> tail 0; emitter -> Ka) ------------------
+            int mat_id = -1;
+            if (hit_k >= 0)
+                mat_id = S.tri_mat[hit_k];
+            const int mrow = (mat_id < 0 ? 0 : mat_id) * MAT_STRIDE;
+            const R *m;
+            if constexpr (TAB)
+                m = lds_mats + mrow;
+            else
+                m = S.mats + mrow;
+            if (mat_id < 0)
+                finished = true, fin_state = uint32_t(bnc) << 16;
+            else if (m[13] != R(0))
+                finished = true, fin_state = (uint32_t(bnc) << 16) | uint32_t(mat_id + 1);
+            else
+            {
+                // ---- shading normal ------------------------------------------------------------------
+                const V3<R> wo = -sd;
+                const R *__restrict__ fn = S.tri_nrm + (size_t)hit_k * 4;
+                const R fn0 = fn[0], fn1 = fn[1], fn2 = fn[2], fn3 = fn[3];
+                V3<R> nrm = {fn0, fn1, fn2};
+                if (fn3 == R(0))
+                {
+                    const int face = S.tri_face[hit_k];
+                    const float *__restrict__ vp = S.verts + (size_t)face * 9;
+                    const float *__restrict__ np = S.normals + (size_t)face * 9;
+                    V3<R> a = {R(vp[0]), R(vp[1]), R(vp[2])}, b = {R(vp[3]), R(vp[4]), R(vp[5])}, c = {R(vp[6]), R(vp[7]), R(vp[8])};
+                    V3<R> w = barycentric(p, a, b, c);
+                    V3<R> acc = w.x * V3<R>{R(np[0]), R(np[1]), R(np[2])};
+                    acc = acc + w.y * V3<R>{R(np[3]), R(np[4]), R(np[5])};
+                    acc = acc + w.z * V3<R>{R(np[6]), R(np[7]), R(np[8])};
+                    nrm = fast_normalized(acc);
+                }
+                // ---- NEE over all lights (sphere lights only: the sampled segment is never tested) ---
+                V3<R> direct = {R(0), R(0), R(0)};
+                for (int l = 0; l < S.n_lights; l++)
+                {
+                    const R *L;
+                    if constexpr (TAB)
+                        L = lds_lights + l * LIGHT_STRIDE;
+                    else
+                        L = S.lights + (size_t)l * LIGHT_STRIDE;
+                    V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
+                    const R x1 = rng_draw<R>(key, sample, bnc, 4 * l + 0);
+                    const R x2 = rng_draw<R>(key, sample, bnc, 4 * l + 1);
+                    const R pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bnc, 4 * l + 2), ro, rd);
+                    if (pdf < R(1e-10))
+                        continue;
+                    const R cn = dot(nrm, -rd);
+                    if (cn < R(0))
+                        continue;
+                    const V3<R> f = bxdf_eval(m, rd, wo, nrm);
+                    const R w = cn / pdf;
+                    direct = direct + V3<R>{(L[1] * w) * f.x, (L[2] * w) * f.y, (L[3] * w) * f.z};
+                }
+                // ---- next direction and indirect coefficient -----------------------------------------
+                V3<R> coef = {R(0), R(0), R(0)};
+                if (S.enable_indirect)
+                {
+                    const R x1 = rng_draw<R>(key, sample, bnc, 4 * S.n_lights + 0);
+                    const R x2 = rng_draw<R>(key, sample, bnc, 4 * S.n_lights + 1);
+                    bxdf_sample(m, nrm, wo, x1, x2, wi, coef);
+                }
+                R *rec = st.stack + ((size_t)s_pid * depth + bnc) * 6;
+                rec[0] = direct.x, rec[1] = direct.y, rec[2] = direct.z;
+                rec[3] = coef.x, rec[4] = coef.y, rec[5] = coef.z;
+                n_rec++;
+                if (S.enable_indirect && bnc + 1 < depth)
+                    cont = true;
+                else
+                    finished = true, fin_state = uint32_t(bnc + 1) << 16;
+            }
+        }
+        hq_head = (hq_head + n) % RING_CAP;
+        hq_count -= n;
+        // continuation rays -> ray ring
+        {
+            const unsigned long long cm = __ballot(cont);
+            if (cont)
+            {
+                const uint32_t r = (rq_head + rq_count + rank_in(cm)) % RING_CAP;
+                Q.ro[r] = p.x, Q.ro[RING_CAP + r] = p.y, Q.ro[2 * RING_CAP + r] = p.z;
+                Q.rd[r] = wi.x, Q.rd[RING_CAP + r] = wi.y, Q.rd[2 * RING_CAP + r] = wi.z;
+                Q.r_pid[r] = s_pid, Q.r_bounce[r] = s_bounce + 1u, Q.r_klo[r] = s_klo, Q.r_khi[r] = s_khi;
+            }
+            rq_count += uint32_t(__popcll(cm));
+        }
+        // finished paths -> resolve
+        {
+            const unsigned long long fm = __ballot(finished);
+            if (finished)
+            {
+                const uint32_t r = (dq_head + dq_count + rank_in(fm)) % DoneQueue::CAP;
+                dq.pid[r] = s_pid, dq.state[r] = fin_state, dq.need[r] = 0u;
+            }
+            dq_count += uint32_t(__popcll(fm));
+            if (dq_count >= 64u)
+                resolve(64u);
+        }
+    };
+
+    for (;;)
+    {
+        // ---- traversal steps until a batch of lanes has a hit to hand over or is free for a ray ----
+        int n_busy, n_done;
+        for (;;)
+        {
+            n_busy = __popcll(__ballot(busy));
+            n_done = __popcll(__ballot(busy && done));
+            const int n_trav = n_busy - n_done;
+            if (n_trav == 0 || n_done >= RING_BATCH)
+                break;
+            if (64 - n_busy >= RING_BATCH && (rq_count > 0u || (!drained && rq_count + hq_count + uint32_t(n_busy) <= uint32_t(RING_ADMIT))))
+                break;
+            const bool act = busy && !done;
+            const bool at_tri = act && T.cur >= S.n_nodes;
+            const int n_tri = __popcll(__ballot(at_tri));
+            if (n_tri * 2 > (n_trav - n_tri) * 3)
+            {
+                if (at_tri)
+                    done = !bvh_step<R, false, 2>(S, o, d, T, stk, n_visit);
+            }
+            else if (act && !at_tri)
+                done = !bvh_step<R, false, 1>(S, o, d, T, stk, n_visit);
+        }
+        // ---- completed traversals -> hit ring -----------------------------------------------------
+        if (n_done >= RING_BATCH || (n_done > 0 && n_busy == n_done))
+        {
+            const bool give = busy && done;
+            const unsigned long long gm = __ballot(give);
+            if (give)
+            {
+                const uint32_t r = (hq_head + hq_count + rank_in(gm)) % RING_CAP;
+                const V3<R> p = o + T.best_t * d;
+                Q.hp[r] = p.x, Q.hp[RING_CAP + r] = p.y, Q.hp[2 * RING_CAP + r] = p.z;
+                Q.hd[r] = d.x, Q.hd[RING_CAP + r] = d.y, Q.hd[2 * RING_CAP + r] = d.z;
+                Q.h_tri[r] = T.target;
+                Q.h_pid[r] = pid, Q.h_bounce[r] = bounce, Q.h_klo[r] = klo, Q.h_khi[r] = khi;
+                busy = false, done = false;
+            }
+            hq_count += uint32_t(__popcll(gm));
+            n_busy -= __popcll(gm);
+        }
+        // ---- 64 hits wait: shade them (fewer only when nothing else is left to do) -----------------
+        if (hq_count >= 64u)
+            shade(64u);
+        else if (hq_count > 0u && n_busy == 0 && rq_count == 0u && drained)
+            shade(hq_count);
+        // ---- camera rays enter through the ray ring, 64 at a time ----------------------------------
+        if (!drained && rq_count < 64u && rq_count + hq_count + uint32_t(n_busy) <= uint32_t(RING_ADMIT))
+        {
+            if (next == end)
+            {
+                uint32_t base = 0;
+                if (lane == 0)
+                    base = atomicAdd(st.pool, uint32_t(chunk));
+                base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+                if (base >= n_paths)
+                    drained = true;
+                else
+                    next = base, end = n_paths - base < uint32_t(chunk) ? n_paths : base + uint32_t(chunk);
+            }
+            const uint32_t cnt = end - next < 64u ? end - next : 64u;
+            if (uint32_t(lane) < cnt)
+            {
+                const uint32_t id = next + uint32_t(lane);
+                const uint32_t pix = id % n_pix;
+                const int lr = B.row0 + int(pix / n_cols), col = B.col0 + int(pix % n_cols);
+                const int row = local_row_to_image_row(B, lr);
+                V3<R> co, cd;
+                primary_ray<R>(cam, col, row, co, cd);
+                const uint64_t key = rng_pixel_key(B.seed, uint32_t(row) * uint32_t(B.image_width) + uint32_t(col));
+                const uint32_t r = (rq_head + rq_count + uint32_t(lane)) % RING_CAP;
+                Q.ro[r] = cam_pos.x, Q.ro[RING_CAP + r] = cam_pos.y, Q.ro[2 * RING_CAP + r] = cam_pos.z;
+                Q.rd[r] = cd.x, Q.rd[RING_CAP + r] = cd.y, Q.rd[2 * RING_CAP + r] = cd.z;
+                Q.r_pid[r] = id, Q.r_bounce[r] = 0u, Q.r_klo[r] = uint32_t(key), Q.r_khi[r] = uint32_t(key >> 32);
+            }
+            next += cnt;
+            rq_count += cnt;
+        }
+        // ---- free lanes take rays --------------------------------------------------------------------
+        if (rq_count > 0u && (64 - n_busy >= RING_BATCH || n_busy == 0 || __popcll(__ballot(busy && !done)) == 0))
+        {
+            ring_sync();
+            const unsigned long long fm = __ballot(!busy);
+            const uint32_t rk = rank_in(fm);
+            if (!busy && rk < rq_count)
+            {
+                const uint32_t r = (rq_head + rk) % RING_CAP;
+                o = {Q.ro[r], Q.ro[RING_CAP + r], Q.ro[2 * RING_CAP + r]};
+                d = {Q.rd[r], Q.rd[RING_CAP + r], Q.rd[2 * RING_CAP + r]};
+                pid = Q.r_pid[r], bounce = Q.r_bounce[r], klo = Q.r_klo[r], khi = Q.r_khi[r];
+                trav_init(T, o, d);
+                busy = true, done = false;
+            }
+            const uint32_t taken = min(uint32_t(__popcll(fm)), rq_count);
+            rq_head = (rq_head + taken) % RING_CAP;
+            rq_count -= taken;
+            n_busy += int(taken);
+        }
+        if (n_busy == 0 && rq_count == 0u && hq_count == 0u && drained)
+            break;
+    }
+    while (dq_count > 0u)
+        resolve(dq_count < 64u ? dq_count : 64u);
+    // per-wave statistics (the wave owns its row)
+    unsigned long long tot[5] = {n_seg, n_rec, n_visit[0], n_visit[1], 0};
+    for (int off = 32; off > 0; off >>= 1)
+        for (int c = 0; c < 4; c++)
+            tot[c] += __shfl_down(tot[c], off, 64);
+    if (lane == 0)
+    {
+        st.wave_stats[g * WAVE_STATS + 0] = tot[0];
+        st.wave_stats[g * WAVE_STATS + 1] = 0;
+        st.wave_stats[g * WAVE_STATS + 2] = n_iter;
+        st.wave_stats[g * WAVE_STATS + 3] = tot[1];
+        st.wave_stats[g * WAVE_STATS + 4] = tot[2];
+        st.wave_stats[g * WAVE_STATS + 5] = tot[3];
+    }
+}
+
+template <bool TAB>
+__global__ void __launch_bounds__(BLOCK, 2) k_trace_rings_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
+{
+    trace_body_rings<double, TAB>(S, cam, B, st, chunk);
+}
+template <bool TAB>
+__global__ void __launch_bounds__(BLOCK, 4) k_trace_rings_f32(DScene<float> S, DCamera cam, DBatch B, DState<float> st, int chunk)
+{
+    trace_body_rings<float, TAB>(S, cam, B, st, chunk);
+}
+
+} // namespace ptx

@@ -82,6 +82,7 @@ template <class R> struct Context::Impl
     DeviceBuffer tri_pre, mats, lights, tri_nrm;
     DeviceBuffer bvh; // 4-wide BVH records (nodes, then the triangles of tri_pre)
     DeviceBuffer spill; // traversal stack levels beyond the LDS ones, [level][lane of the launch]
+    DeviceBuffer rings; // ray and hit rings of the ring tracer, one region per wave of the launch
     DeviceBuffer state_mem; // one slab carved into the DState arrays
     DState<R> st;
     int64_t capacity = 0;
@@ -269,6 +270,7 @@ template <class R> struct Context::Impl
         st.wave_stats = reinterpret_cast<unsigned long long *>(base + o_ws);
         st.stats = reinterpret_cast<unsigned long long *>(base + o_stats);
         st.pool = reinterpret_cast<unsigned int *>(base + o_pool);
+        st.rings = nullptr;
         st.N = n;
         st.n_waves = 0;
         capacity = n;
@@ -549,10 +551,11 @@ template <class R> struct TracePlan
     int blocks_per_cu = 1;
     size_t dyn_lds = 0; // bytes of traversal stacks per workgroup (BVH kernels)
     int stack_levels = 0; // levels of them
+    bool rings = false;   // the ring tracer (needs DState::rings)
 };
 
 template <class R, bool BRUTE>
-static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shadow_queue, int stack_need, int lds_stack_cap)
+static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shadow_queue, int stack_need, int lds_stack_cap, bool rings = false)
 {
     TracePlan<R> p;
     const bool tab = S.n_mats <= LDS_MATS && S.n_lights <= LDS_LIGHTS;
@@ -579,6 +582,15 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
         pick(std::true_type());
     else
         pick(std::false_type());
+    if (!BRUTE && lights == 0 && rings)
+    {
+        // no visibility tests at all: the tracer that keeps more paths in flight than lanes
+        p.rings = true;
+        if constexpr (sizeof(R) == 8)
+            p.kernel = tab ? k_trace_rings_f64<true> : k_trace_rings_f64<false>;
+        else
+            p.kernel = tab ? k_trace_rings_f32<true> : k_trace_rings_f32<false>;
+    }
     // BVH kernels: how many stack levels to keep in LDS.  The registers (and the static LDS)
     // allow `by_regs` workgroups per CU; the stacks get what is left of the CU's LDS at that
     // occupancy, as long as that is a useful depth, and deeper levels spill to global memory.
@@ -749,7 +761,15 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     RenderTimers *tm = o.profile ? &timers_ : nullptr;
     // The grid of the tracer is just large enough to fill the device: its waves are persistent.
     const TracePlan<R> plan = brute_ ? plan_trace<R, true>(S, trace_blocks_per_cu, shadow_queue, 0, 0)
-                                    : plan_trace<R, false>(S, trace_blocks_per_cu, shadow_queue, geo_->stack_need, lds_stack_levels);
+                                    : plan_trace<R, false>(S, trace_blocks_per_cu, shadow_queue, geo_->stack_need, lds_stack_levels, bvh_rings);
+    if (plan.rings)
+    {
+        const int64_t waves = std::min<int64_t>(static_cast<int64_t>(plan.blocks_per_cu) * n_cus_, MAX_TRACE_WAVES / (BLOCK / 64)) * (BLOCK / 64);
+        const size_t bytes = static_cast<size_t>(waves) * ring_bytes<R>();
+        if (im.rings.bytes < bytes)
+            im.rings.alloc(bytes);
+        im.st.rings = static_cast<char *>(im.rings.p);
+    }
     if (!brute_)
     {
         // stack levels the LDS does not hold: one column per lane of the launch in global memory

@@ -91,6 +91,7 @@ template <class R> struct DState
     unsigned long long *wave_stats; // [n_waves][WAVE_STATS] segments, shadow tests, wave iterations, records, BVH node visits, BVH triangle visits
     unsigned long long *stats;      // [8] totals (filled by k_reduce_stats)
     unsigned int *pool;             // next unassigned path id of the current batch
+    char *rings;                    // [n_waves][ring_bytes<R>()] ray and hit rings of the ring tracer (BVH scenes)
     int64_t N;                      // capacity (paths per batch)
     int n_waves;                    // waves of the current batch
 };
@@ -1172,6 +1173,11 @@ __global__ void __launch_bounds__(BLOCK, BRUTE ? 4 : 3) k_trace_f32(DScene<float
 {
     trace_body<float, BRUTE, TAB, LIGHTS>(S, cam, B, st, chunk);
 }
+
+} // namespace ptx
+#include "bvh_tracer.hpp"
+namespace ptx
+{
 
 // one thread per pixel of the batch: continues the running per-pixel sum in sample order
 template <class R> __global__ void __launch_bounds__(BLOCK) k_accumulate(DBatch B, DState<R> st, double *__restrict__ sum)

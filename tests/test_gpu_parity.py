@@ -260,6 +260,31 @@ def test_bvh_stack_spill_is_bit_invariant(root, conf, kw):
         assert np.array_equal(base, imgs[("f64",)][0])
 
 
+@pytest.mark.parametrize("conf,kw", [("config/mis.conf", dict(width=160, height=96, spp=8)),
+                                     ("config/room.conf", dict(width=96, height=64, spp=3))])
+def test_ring_tracer_equals_lane_tracer(root, conf, kw):
+    """BVH scenes without square lights: the tracer that queues hits and rays per wave (more paths in
+    flight than lanes) and the one that keeps every path on its lane render the same bits and
+    visit the same BVH records, whatever the grid and the LDS share of the stacks."""
+    s, ref = load(root, conf, **kw)
+    out = {}
+    for rings, extra in ((0, {}), (1, {}), (1, dict(trace_blocks_per_cu=1, lds_stack_levels=4)), (1, dict(chunk_paths=4096))):
+        c = pt.Context(0)
+        c.set_option("bvh_rings", rings)
+        for k, v in extra.items():
+            c.set_option(k, v)
+        c.build_accel(s)
+        assert not c.accel_info()["brute_force"]
+        for mode in ("f64", "f32"):
+            img, st = c.render(mode=mode)
+            if mode in out:
+                assert np.array_equal(img, out[mode][0]), (rings, extra, mode)
+                for k in ("segments", "records", "bvh_nodes", "bvh_tris", "paths"):
+                    assert st[k] == out[mode][1][k], (k, rings, extra, mode)
+            else:
+                out[mode] = (img, st)
+
+
 def test_render_f32_meets_rmse_bar(root):
     s, ref = load(root, "config/cbox.conf", width=64, height=64, spp=16)
     c = make_ctx(s)
