@@ -21,7 +21,8 @@ namespace ptx
 
 constexpr int RING_CAP = 256;       // entries of either ring
 constexpr int RING_ADMIT = 128;     // camera rays are admitted while at most this many paths are in flight
-constexpr int RING_BATCH = 16;      // lanes that hand over hits / take rays together
+constexpr int RING_BATCH = 40;      // lanes that hand over hits / take rays together (a hand-over drains the
+                                    // wave's outstanding loads; measured plateau: 32 to 48)
 
 // bytes of one wave's two rings
 template <class R> constexpr size_t ring_bytes() { return size_t(RING_CAP) * (12 * sizeof(R) + 4 * 9); }
