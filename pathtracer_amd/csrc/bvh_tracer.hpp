@@ -408,7 +408,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
 }
 
 template <bool TAB>
-__global__ void __launch_bounds__(BLOCK, 2) k_trace_rings_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
+__global__ void __launch_bounds__(BLOCK, 3) k_trace_rings_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
 {
     trace_body_rings<double, TAB>(S, cam, B, st, chunk);
 }

@@ -620,9 +620,14 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
             while (lv >= useful)
             {
                 HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, p.kernel, BLOCK, static_cast<size_t>(lv) * BLOCK * 4));
-                if (got >= b)
+                // LDS is handed out in granules of 1280 bytes on this device, which the calculator
+                // does not round to (measured: 3 x 54272 bytes do not fit 160 KB, 3 x 53760 do)
+                const int granule = 1280;
+                const int per_block = (static_cast<int>(fa.sharedSizeBytes) + lv * BLOCK * 4 + granule - 1) / granule * granule;
+                if (got >= b && per_block * b <= lds_cu)
                     break;
-                lv--; // allocation granularity
+                got = 0;
+                lv--;
             }
             if (lv >= useful && got >= b)
             {

@@ -1166,7 +1166,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
 // runs 2 waves per SIMD (up to 256 vector registers) -- 3 (168 registers) when the visibility
 // tests are queued, which takes their live range out of the shading code -- the f32 tracer 4 (128).
 template <bool BRUTE, bool TAB, int LIGHTS>
-__global__ void __launch_bounds__(BLOCK, LIGHTS == 1 ? 3 : 2) k_trace_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
+__global__ void __launch_bounds__(BLOCK, (LIGHTS == 1 || !BRUTE) ? 3 : 2) k_trace_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
 {
     trace_body<double, BRUTE, TAB, LIGHTS>(S, cam, B, st, chunk);
 }
