@@ -1,6 +1,6 @@
-// Host-built 4-wide BVH.  A binned-SAH binary tree with one triangle per leaf is built first and then
-// collapsed: every 4-wide node adopts grandchildren of the binary tree (largest box first) until
-// it has four children.  One 128-byte node carries the boxes of all its children, so a traversal
+// Host-built 4-wide BVH.  A binned-SAH binary tree with leaves of up to four triangles is built first
+// and then collapsed: every 4-wide node adopts, largest box first, the children of its inner children
+// and the triangles of its leaf children until it has four children.  One 128-byte node carries the boxes of all its children, so a traversal
 // step is one aligned 128-B fetch followed by four slab tests; triangles are children like any
 // other (their box is the triangle's own), fetched and tested exactly when they are visited.
 #pragma once

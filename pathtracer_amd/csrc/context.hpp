@@ -77,7 +77,6 @@ public:
     // scenes up to this many triangles are intersected by the all-triangles loop
     int brute_force_limit = 64;
     int64_t default_batch_paths = int64_t(1) << 26;
-    // largest number of triangles in a BVH leaf (1..8)
     // path ids a wave of the tracer takes from the pool at a time (>= 64)
     int chunk_paths = 64;
     // workgroups of the tracer per compute unit (<= 0: what the occupancy calculator reports)

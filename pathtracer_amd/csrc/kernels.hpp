@@ -1,13 +1,14 @@
 // Path-tracing kernels for gfx950 (wave64).  Templated on the scalar type R and on the intersector
 // (BRUTE: two-phase all-triangles test -- f32 plane records from a wave-uniform table the compiler
-// reads through the scalar cache, then the exact test on the survivors; otherwise the flattened
-// BVH with a per-lane LDS stack).
+// reads through the scalar cache, then the exact test on the survivors; otherwise the 4-wide BVH
+// with a per-lane stack in LDS).
 //
 // Kernel <-> reference map (paths relative to the reference root):
 //   primary_ray / k_camera_rays  cPathTracer::GenerateRay        src/tracing/cPathTracer.cpp:129-213
 //   closest_hit / k_raycast .... cAccelStruct::RayCast           src/geometry/cAccelStruct.cpp:28-54
 //   visible / k_vistest ........ cAccelStruct::VisTest           src/geometry/cAccelStruct.cpp:56-87
-//   k_trace_f64 / k_trace_f32 .. the bounce loop of one primary ray, cPathTracer.cpp:555-673:
+//   k_trace_f64 / k_trace_f32,   the bounce loop of one primary ray, cPathTracer.cpp:555-673:
+//   k_trace_rings_* (bvh_tracer.hpp)
 //                                RayCast, miss / emitter termination, shading normal, NEE over all
 //                                lights with their VisTest (cBxDF::Sample_Li, src/tracing/cBxDF.cpp:
 //                                16-52), next direction (Sample_f); one (direct, coefficient) record
@@ -698,11 +699,12 @@ struct DoneQueue
 // goes through the wave's ShadowQueue (all-triangles intersector only); 2 -- tests run in place.
 //
 // With the BVH the closest-hit search is a per-lane loop of very uneven length (on the 336 k
-// triangle room: 16 node visits on average, 91 for the slowest lane of a wave), so it is not run to
-// completion inside one bounce iteration.  Every lane keeps a resumable traversal; the wave advances
-// all unfinished traversals one node at a time and only turns to shading -- and to starting new
-// paths -- when enough lanes are waiting for it.  Lanes with a long traversal simply keep going
-// while the others shade, start their next ray and catch up.
+// triangle room: 21 records on average, several times that for the slowest lane of a wave), so it
+// is not run to completion inside one bounce iteration.  Every lane keeps a resumable traversal;
+// the wave advances all unfinished traversals one record at a time and only turns to shading --
+// and to starting new paths -- when enough lanes are waiting for it.  Lanes with a long traversal
+// simply keep going while the others shade, start their next ray and catch up.  (BVH scenes
+// without square lights use the ring tracer of bvh_tracer.hpp instead.)
 template <class R, bool BRUTE, bool TAB, int LIGHTS>
 __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &cam, const DBatch &B, const DState<R> &st, int chunk)
 {
