@@ -134,3 +134,38 @@ def test_intersector_hand_over_at_the_record_limit(cbox):
         assert (quads == 18) == (n_recs <= 32)
         assert_f64_parity(img, oimg, st, ost)
         assert np.array_equal(c.first_hit(), oracle.Oracle(ref).first_hit())
+
+
+# ---- BVH scenes without square lights: the ring tracer (hits and rays queue per wave) -------------
+@pytest.fixture()
+def mis(root):
+    return scene_io.load_conf(os.path.join(root, "config/mis.conf"), root_dir=root, width=48, height=32, spp=3)
+
+
+@pytest.mark.parametrize("depth", [1, 2, 40])
+def test_ring_tracer_extreme_depths(mis, depth):
+    ref = copy.deepcopy(mis)
+    ref.depth = depth
+    img, st, oimg, ost, c = render_both(ref)
+    assert not c.accel_info()["brute_force"]
+    assert_f64_parity(img, oimg, st, ost, depth=depth)
+
+
+@pytest.mark.parametrize("w,h,spp", [(1, 1, 1), (5, 3, 1), (9, 7, 33)])
+def test_ring_tracer_fewer_paths_than_lanes_and_ragged_counts(root, w, h, spp):
+    ref = scene_io.load_conf(os.path.join(root, "config/mis.conf"), root_dir=root, width=w, height=h, spp=spp)
+    img, st, oimg, ost, _ = render_both(ref)
+    assert st["paths"] == w * h * spp
+    assert_f64_parity(img, oimg, st, ost)
+
+
+def test_ring_tracer_without_lights_and_without_indirect_light(mis):
+    ref = copy.deepcopy(mis)
+    ref.lights = np.zeros((0, 16))
+    img, st, oimg, ost, _ = render_both(ref)
+    assert_f64_parity(img, oimg, st, ost)
+    ref = copy.deepcopy(mis)
+    ref.enable_indirect = False
+    img, st, oimg, ost, _ = render_both(ref)
+    assert_f64_parity(img, oimg, st, ost)
+    assert st["segments"] == st["paths"]                      # one segment per path: no continuation rays
