@@ -80,7 +80,7 @@ inline unsigned blocks_for(int64_t n) { return static_cast<unsigned>(std::max<in
 template <class R> struct Context::Impl
 {
     DeviceBuffer tri_pre, mats, lights, tri_nrm;
-    DeviceBuffer bvh; // 4-wide BVH records (nodes, then the triangles of tri_pre)
+    DeviceBuffer bvh; // triangle records of the 4-wide BVH
     DeviceBuffer spill; // traversal stack levels beyond the LDS ones, [level][lane of the launch]
     DeviceBuffer rings; // ray and hit rings of the ring tracer, one region per wave of the launch
     DeviceBuffer state_mem; // one slab carved into the DState arrays
@@ -116,30 +116,19 @@ template <class R> struct Context::Impl
         }
         upload(tri_pre, pre, s);
 
-        // 4-wide BVH records, 32 dwords each: nodes carry child boxes and child record ids,
-        // triangle records the 12 scalars above and the face id in dword 24
-        const size_t n_nodes = bvh.nodes.size();
-        std::vector<uint32_t> recs((n_nodes + static_cast<size_t>(std::max(F, 0))) * 32, 0u);
-        for (size_t i = 0; i < n_nodes; i++)
+        // triangle records of the BVH, intersector order: p1, p1-p2, p1-p3 (9 scalars), face id
         {
-            const BvhNode &nd = bvh.nodes[i];
-            uint32_t *o = &recs[i * 32];
-            std::memcpy(o, nd.lo, 48);
-            std::memcpy(o + 12, nd.hi, 48);
-            for (int j = 0; j < 4; j++)
-            {
-                const int32_t ch = nd.child[j];
-                o[24 + j] = ch == BVH_EMPTY ? 0xFFFFFFFFu : ch >= 0 ? static_cast<uint32_t>(ch) : static_cast<uint32_t>(n_nodes + static_cast<size_t>(~ch));
-            }
+            const int stride = (sizeof(R) == 8 ? 5 : 3) * 4; // dwords
+            std::vector<uint32_t> recs(static_cast<size_t>(std::max(brute ? 0 : F, 1)) * stride, 0u);
+            if (!brute)
+                for (int k = 0; k < F; k++)
+                {
+                    uint32_t *o = &recs[static_cast<size_t>(k) * stride];
+                    std::memcpy(o, &pre[static_cast<size_t>(k) * 12], 9 * sizeof(R));
+                    o[9 * sizeof(R) / 4] = static_cast<uint32_t>(bvh.tri_order[k]);
+                }
+            upload(this->bvh, recs, s);
         }
-        if (!brute)
-            for (int k = 0; k < F; k++)
-            {
-                uint32_t *o = &recs[(n_nodes + static_cast<size_t>(k)) * 32];
-                std::memcpy(o, &pre[static_cast<size_t>(k) * 12], 12 * sizeof(R));
-                o[24] = static_cast<uint32_t>(bvh.tri_order[k]);
-            }
-        upload(this->bvh, recs, s);
 
         std::vector<R> m(static_cast<size_t>(std::max<size_t>(sc.mats.size(), 1)) * MAT_STRIDE, R(0));
         for (size_t i = 0; i < sc.mats.size(); i++)
@@ -280,13 +269,81 @@ template <class R> struct Context::Impl
 
 struct Context::Geometry
 {
-    DeviceBuffer tri_face, tri_mat, verts, normals, mat_ids;
+    DeviceBuffer tri_face, tri_mat, verts, normals, mat_ids, nodes;
     DeviceBuffer tri_pq, rec_tri, tri_rec, rec_block; // plane records of the all-triangles intersector
     int n_recs = 0;
     float smax = 0.f;
     int n_nodes = 0, id_bits = 1; // 4-wide BVH: node records, bits of the record id in a stack entry
     int stack_need = 1;           // stack entries a traversal can need
 };
+
+// 64-byte device nodes: corner and cell size of an 8-bit grid over the union of the child boxes,
+// the child boxes in grid coordinates (rounded outward), the child record ids (nodes first, then
+// triangles; 0xFFFFFFFF: no child).  Word layout: corner.xyz, id0 | cell.xyz, id1 | x lo, x hi, y lo,
+// y hi | z lo, z hi, id2, id3; the six coordinate words hold one byte per child.
+static std::vector<uint32_t> pack_nodes(const Bvh &bvh, int n_tris)
+{
+    const size_t n_nodes = bvh.nodes.size();
+    std::vector<uint32_t> out(std::max<size_t>(n_nodes, 1) * 16, 0u);
+    for (size_t i = 0; i < n_nodes; i++)
+    {
+        const BvhNode &nd = bvh.nodes[i];
+        uint32_t *o = &out[i * 16];
+        uint32_t id[4];
+        for (int j = 0; j < 4; j++)
+        {
+            const int32_t ch = nd.child[j];
+            id[j] = ch == BVH_EMPTY ? 0xFFFFFFFFu : ch >= 0 ? static_cast<uint32_t>(ch) : static_cast<uint32_t>(n_nodes + static_cast<size_t>(~ch));
+        }
+        uint32_t q[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+        float corner[3], cell[3];
+        for (int k = 0; k < 3; k++)
+        {
+            float lo = std::numeric_limits<float>::infinity(), hi = -std::numeric_limits<float>::infinity();
+            for (int j = 0; j < 4; j++)
+                if (nd.child[j] != BVH_EMPTY)
+                    lo = std::min(lo, nd.lo[k][j]), hi = std::max(hi, nd.hi[k][j]);
+            if (!(lo <= hi))
+                lo = hi = 0.f; // a node without children
+            // cell >= extent / 255 in exact arithmetic, so that coordinate 255 reaches the far side
+            float cs = static_cast<float>((static_cast<double>(hi) - lo) / 255.0);
+            while (static_cast<double>(lo) + 255.0 * cs < hi)
+                cs = std::nextafter(cs, std::numeric_limits<float>::infinity());
+            if (!(cs > 0.f))
+                cs = std::numeric_limits<float>::min();
+            corner[k] = lo, cell[k] = cs;
+            for (int j = 0; j < 4; j++)
+            {
+                int ql = 255, qh = 0; // an absent child: an inverted slab
+                if (nd.child[j] != BVH_EMPTY)
+                {
+                    // outward rounding, checked in exact (double) arithmetic on the float corner and cell
+                    ql = static_cast<int>(std::floor((static_cast<double>(nd.lo[k][j]) - lo) / cs));
+                    qh = static_cast<int>(std::ceil((static_cast<double>(nd.hi[k][j]) - lo) / cs));
+                    ql = std::min(std::max(ql, 0), 255), qh = std::min(std::max(qh, 0), 255);
+                    while (ql > 0 && static_cast<double>(lo) + static_cast<double>(ql) * cs > nd.lo[k][j])
+                        ql--;
+                    while (qh < 255 && static_cast<double>(lo) + static_cast<double>(qh) * cs < nd.hi[k][j])
+                        qh++;
+                    if (static_cast<double>(lo) + static_cast<double>(ql) * cs > nd.lo[k][j] ||
+                        static_cast<double>(lo) + static_cast<double>(qh) * cs < nd.hi[k][j])
+                        throw std::runtime_error("state: BVH node quantisation is not conservative");
+                }
+                q[k][0] |= static_cast<uint32_t>(ql) << (8 * j);
+                q[k][1] |= static_cast<uint32_t>(qh) << (8 * j);
+            }
+        }
+        std::memcpy(&o[0], corner, 12);
+        o[3] = id[0];
+        std::memcpy(&o[4], cell, 12);
+        o[7] = id[1];
+        o[8] = q[0][0], o[9] = q[0][1], o[10] = q[1][0], o[11] = q[1][1];
+        o[12] = q[2][0], o[13] = q[2][1], o[14] = id[2], o[15] = id[3];
+    }
+    (void)n_tris;
+    return out;
+}
+
 
 Context::Context(int device) : device_(device)
 {
@@ -368,6 +425,7 @@ void Context::build_accel(const Scene &sc)
     upload(geo_->verts, sc.verts, s);
     upload(geo_->normals, sc.normals, s);
     upload(geo_->mat_ids, sc.mat_ids, s);
+    upload(geo_->nodes, pack_nodes(bvh_, sc.n_tris()), s);
     upload(geo_->tri_pq, pr.rec, s);
     upload(geo_->rec_tri, pr.rec_tri, s);
     upload(geo_->tri_rec, pr.tri_rec, s);
@@ -420,7 +478,8 @@ template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::
     S.lights = static_cast<const R *>(lights);
     S.tri_nrm = static_cast<const R *>(tri_nrm);
     S.tri_mat = static_cast<const int32_t *>(g.tri_mat.p);
-    S.bvh = static_cast<const uint4 *>(bvh);
+    S.bvh_nodes = static_cast<const uint4 *>(g.nodes.p);
+    S.bvh_tris = static_cast<const uint4 *>(bvh);
     S.n_nodes = g.n_nodes, S.id_bits = g.id_bits;
     S.stack_levels = g.stack_need; // the operator kernels keep the whole stack in LDS
     S.spill_stride = 0;

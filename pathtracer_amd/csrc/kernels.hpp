@@ -47,7 +47,8 @@ template <class R> struct DScene
     const R *lights;           // [n_lights][LIGHT_STRIDE]
     const R *tri_nrm;          // [n_tris][4] intersector order: shading normal + flag (1: use it; 0: interpolate)
     const int32_t *tri_mat;    // [n_tris] intersector order: material id (-1: none)
-    const uint4 *bvh;          // [n_nodes + n_tris][8] 4-wide BVH records: nodes, then triangles in intersector order
+    const uint4 *bvh_nodes;    // [n_nodes][4] 64-byte nodes of the 4-wide BVH (child boxes quantised to 8 bits)
+    const uint4 *bvh_tris;     // [n_tris][5 (f64) or 3 (f32)] triangle records in intersector order: p1, p1-p2, p1-p3, face id
     int n_nodes, id_bits;      // id_bits: bits of a stack entry that hold the record id
     int stack_levels;          // traversal stack levels held in LDS; deeper levels go to `spill`
     int spill_stride;          // lanes of the launch
@@ -249,18 +250,25 @@ __device__ __forceinline__ unsigned long long drop_own_plane(unsigned long long 
 }
 
 // ---------------------------------------------------------------------------------------------
-// 4-wide BVH.  The tree is one array of 128-byte records: nodes first (four child boxes by axis in
-// f32, four child record ids), then one record per triangle (its 12 scalars of the exact test in
-// R, its face id in dword 24).  A traversal step fetches ONE record and either runs four slab
-// tests (node) or the exact test (triangle), so every step costs one memory round trip whatever
-// mix of nodes and triangles the lanes of a wave are at.
+// 4-wide BVH.  Nodes are 64 bytes: the corner and cell size of an 8-bit grid laid over the union of
+// the child boxes, the child boxes in grid coordinates (rounded outward by the host, which checks
+// it in exact arithmetic), four child record ids.  Triangles are records of their own (the 9
+// scalars p1, p1-p2, p1-p3 of the exact test in R and the face id: 80 bytes in f64, 48 in f32).  A
+// traversal step fetches ONE record and either runs four slab tests (node: four 16-byte loads per
+// lane) or the exact test (triangle: five, or three), so every step costs one memory round trip,
+// and as few vector-cache accesses as the data allows -- with 64 lanes at 64 different records it
+// is the number of load instructions per step, not the bytes, that the memory pipeline feels
+// (128-byte records with full-precision boxes and precomputed cofactors: 8 % slower on the 336 k
+// triangle room; doubling the footprint of the tree instead changes nothing).
 //
 // The slab tests run in f32 against an interval around the ray origin that contains the true origin
 // (rounding it to f32 moves it by at most 2^-24 of its magnitude; the interval is 2^-22 wide per
-// side) and only ever make a box look nearer and longer: entry distances are lower bounds, scaled
-// down by 2^-20 to absorb the roundings of the test itself, so a box that holds a triangle whose
-// exact distance could win or tie is never skipped, and hits, distances and ties are those of
-// testing every triangle exactly.
+// side) and only ever make a box look nearer and longer: plane distances are computed as
+// (cell * slope) * coordinate + (corner - origin) * slope, near planes from the end of the origin
+// interval that makes them nearer and lowered by a bound of the roundings of that sum, far planes
+// the other way round, and entry distances are scaled down by another 2^-20.  So a box that holds
+// a triangle whose exact distance could win or tie is never skipped, and hits, distances and ties
+// are those of testing every triangle exactly.
 //
 // Stack entries pack the (truncated, hence still lower-bound) entry distance above the record id
 // (S.id_bits bits): children are ordered by sorting their entries, and an entry whose distance has
@@ -268,11 +276,11 @@ __device__ __forceinline__ unsigned long long drop_own_plane(unsigned long long 
 // ---------------------------------------------------------------------------------------------
 template <class R> struct Trav
 {
-    int cur;      // record to visit next
+    int cur;      // record to visit next (< S.n_nodes: node, else triangle cur - S.n_nodes)
     int sp, target, best_face;
     R best;       // closest accepted distance so far (any-hit: length of the segment)
     R best_t;     // ray parameter of that hit: the hit point is o + best_t * d
-    float ohx, ohy, ohz, olx, oly, olz; // upper / lower end of the origin interval
+    float onx, ony, onz, ofx, ofy, ofz; // end of the origin interval that makes the near / far plane of a slab nearer / farther
     float ivx, ivy, ivz;                // 1 / d, finite
 };
 template <class R> __device__ __forceinline__ void trav_init(Trav<R> &T, V3<R> o, V3<R> d, R limit = Consts<R>::big)
@@ -282,33 +290,60 @@ template <class R> __device__ __forceinline__ void trav_init(Trav<R> &T, V3<R> o
     T.best_t = R(0);
     const float fx = float(o.x), fy = float(o.y), fz = float(o.z);
     const float P = 0x1p-22f * fmaxf(fmaxf(fabsf(fx), fabsf(fy)), fabsf(fz)) + 1e-30f;
-    T.ohx = fx + P, T.ohy = fy + P, T.ohz = fz + P;
-    T.olx = fx - P, T.oly = fy - P, T.olz = fz - P;
-    const float big = 3.0e38f; // an axis the ray does not move along: a huge finite slope keeps 0 * inf out of the slabs
+    const float big = 1.0e18f; // an axis the ray does not move along: a huge finite slope keeps infinities out of the slabs
     // 1 / d from the f32 reciprocal instruction (1 ulp) of the rounded direction: 1.5 * 2^-23 in
-    // all, well inside the 2^-20 by which bvh_step widens every slab
+    // all, well inside the margins by which bvh_step widens every slab
     T.ivx = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(float(d.x)), -big, big);
     T.ivy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(float(d.y)), -big, big);
     T.ivz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(float(d.z)), -big, big);
+    // (plane - origin) * slope gets smaller with the upper end of the interval when the slope is
+    // positive, with the lower end when it is negative
+    T.onx = T.ivx >= 0.0f ? fx + P : fx - P, T.ofx = T.ivx >= 0.0f ? fx - P : fx + P;
+    T.ony = T.ivy >= 0.0f ? fy + P : fy - P, T.ofy = T.ivy >= 0.0f ? fy - P : fy + P;
+    T.onz = T.ivz >= 0.0f ? fz + P : fz - P, T.ofz = T.ivz >= 0.0f ? fz - P : fz + P;
 }
 
-__device__ __forceinline__ void unpack_tri(double *tri, const uint4 &q0, const uint4 &q1, const uint4 &q2, const uint4 &q3,
-                                           const uint4 &q4, const uint4 &q5)
+// triangle record -> the 12 scalars of the exact test (the three cofactors that do not involve
+// the ray are recomputed with the operations the host uses for the all-triangles table)
+__device__ __forceinline__ void finish_tri(double *t)
 {
+    double t0 = t[4] * t[8], t1 = t[7] * t[5];
+    t[9] = t0 - t1;
+    t0 = t[5] * t[6], t1 = t[8] * t[3];
+    t[10] = t0 - t1;
+    t0 = t[3] * t[7], t1 = t[6] * t[4];
+    t[11] = t0 - t1;
+}
+__device__ __forceinline__ void finish_tri(float *t)
+{
+    float t0 = t[4] * t[8], t1 = t[7] * t[5];
+    t[9] = t0 - t1;
+    t0 = t[5] * t[6], t1 = t[8] * t[3];
+    t[10] = t0 - t1;
+    t0 = t[3] * t[7], t1 = t[6] * t[4];
+    t[11] = t0 - t1;
+}
+__device__ __forceinline__ int load_tri(const uint4 *rec, double *tri)
+{
+    const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
     tri[0] = __hiloint2double(int(q0.y), int(q0.x)), tri[1] = __hiloint2double(int(q0.w), int(q0.z));
     tri[2] = __hiloint2double(int(q1.y), int(q1.x)), tri[3] = __hiloint2double(int(q1.w), int(q1.z));
     tri[4] = __hiloint2double(int(q2.y), int(q2.x)), tri[5] = __hiloint2double(int(q2.w), int(q2.z));
     tri[6] = __hiloint2double(int(q3.y), int(q3.x)), tri[7] = __hiloint2double(int(q3.w), int(q3.z));
-    tri[8] = __hiloint2double(int(q4.y), int(q4.x)), tri[9] = __hiloint2double(int(q4.w), int(q4.z));
-    tri[10] = __hiloint2double(int(q5.y), int(q5.x)), tri[11] = __hiloint2double(int(q5.w), int(q5.z));
+    tri[8] = __hiloint2double(int(q4.y), int(q4.x));
+    finish_tri(tri);
+    return int(q4.z);
 }
-__device__ __forceinline__ void unpack_tri(float *tri, const uint4 &q0, const uint4 &q1, const uint4 &q2, const uint4 &,
-                                           const uint4 &, const uint4 &)
+__device__ __forceinline__ int load_tri(const uint4 *rec, float *tri)
 {
+    const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
     tri[0] = __uint_as_float(q0.x), tri[1] = __uint_as_float(q0.y), tri[2] = __uint_as_float(q0.z), tri[3] = __uint_as_float(q0.w);
     tri[4] = __uint_as_float(q1.x), tri[5] = __uint_as_float(q1.y), tri[6] = __uint_as_float(q1.z), tri[7] = __uint_as_float(q1.w);
-    tri[8] = __uint_as_float(q2.x), tri[9] = __uint_as_float(q2.y), tri[10] = __uint_as_float(q2.z), tri[11] = __uint_as_float(q2.w);
+    tri[8] = __uint_as_float(q2.x);
+    finish_tri(tri);
+    return int(q2.y);
 }
+template <class R> constexpr int tri_rec_q() { return sizeof(R) == 8 ? 5 : 3; } // 16-byte words of a triangle record
 
 // The two homes of a stack level, addressed through explicit address spaces: left generic, the
 // compiler merges the two stores of a push into one flat store behind a pointer select.
@@ -326,15 +361,13 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
 {
     constexpr float K = 0x1p-20f;
     const R self_eps = Consts<R>::self_eps;
-    const uint4 *rec = S.bvh + (size_t)T.cur * 8;
-    const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
     const int id_bits = S.id_bits;
     uint32_t next = 0xFFFFFFFFu;
     if (KIND == 2 || (KIND == 0 && T.cur >= S.n_nodes))
     {
         visits[1]++;
         R tri[12], t;
-        unpack_tri(tri, q0, q1, q2, q3, q4, q5);
+        const int face = load_tri(S.bvh_tris + (size_t)(T.cur - S.n_nodes) * tri_rec_q<R>(), tri);
         if (tri_test(tri, o, d, t))
         {
             if (ANY)
@@ -347,7 +380,6 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
             }
             else
             {
-                const int face = int(q6.x);
                 V3<R> p = o + t * d;
                 R dist = norm(p - o);
                 if (dist > self_eps && (dist < T.best || (dist == T.best && face < T.best_face)))
@@ -363,21 +395,42 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
     else
     {
         visits[0]++;
+        // 64-byte node: corner and cell size of the 8-bit grid its child boxes are quantised to,
+        // six words of grid coordinates (low and high plane per axis, one byte per child), four ids
+        const uint4 *rec = S.bvh_nodes + (size_t)T.cur * 4;
+        const uint4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
         const float tmaxf = float(T.best) * (1.0f + K) + 1e-30f;
-        auto slab = [&](uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint32_t hy, uint32_t hz, uint32_t child) {
-            const float ax = (__uint_as_float(lx) - T.ohx) * T.ivx, bx = (__uint_as_float(hx) - T.olx) * T.ivx;
-            const float ay = (__uint_as_float(ly) - T.ohy) * T.ivy, by = (__uint_as_float(hy) - T.oly) * T.ivy;
-            const float az = (__uint_as_float(lz) - T.ohz) * T.ivz, bz = (__uint_as_float(hz) - T.olz) * T.ivz;
-            float tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), 0.0f);
-            const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        // plane distance t = A * q + B per axis, A = cell * slope, B = (corner - origin) * slope, with
+        // the origin end and the plane (low or high) that make a near plane nearer and a far plane
+        // farther; the roundings of A, B and of the sum are bounded by 2^-21 (255 |A| + |B|), which
+        // is taken off the near planes and added to the far ones
+        const float Ax = __uint_as_float(n1.x) * T.ivx, Ay = __uint_as_float(n1.y) * T.ivy, Az = __uint_as_float(n1.z) * T.ivz;
+        float Bnx = (__uint_as_float(n0.x) - T.onx) * T.ivx, Bfx = (__uint_as_float(n0.x) - T.ofx) * T.ivx;
+        float Bny = (__uint_as_float(n0.y) - T.ony) * T.ivy, Bfy = (__uint_as_float(n0.y) - T.ofy) * T.ivy;
+        float Bnz = (__uint_as_float(n0.z) - T.onz) * T.ivz, Bfz = (__uint_as_float(n0.z) - T.ofz) * T.ivz;
+        constexpr float M = 0x1p-21f;
+        const float mx = M * (255.0f * fabsf(Ax) + fmaxf(fabsf(Bnx), fabsf(Bfx)));
+        const float my = M * (255.0f * fabsf(Ay) + fmaxf(fabsf(Bny), fabsf(Bfy)));
+        const float mz = M * (255.0f * fabsf(Az) + fmaxf(fabsf(Bnz), fabsf(Bfz)));
+        Bnx -= mx, Bfx += mx, Bny -= my, Bfy += my, Bnz -= mz, Bfz += mz;
+        const bool px = T.ivx >= 0.0f, py = T.ivy >= 0.0f, pz = T.ivz >= 0.0f;
+        const uint32_t qnx = px ? n2.x : n2.y, qfx = px ? n2.y : n2.x; // near / far plane coordinates of the four children
+        const uint32_t qny = py ? n2.z : n2.w, qfy = py ? n2.w : n2.z;
+        const uint32_t qnz = pz ? n3.x : n3.y, qfz = pz ? n3.y : n3.x;
+        auto slab = [&](int i, uint32_t child) {
+            const float tnx = fmaf(Ax, float((qnx >> (8 * i)) & 255u), Bnx), tfx = fmaf(Ax, float((qfx >> (8 * i)) & 255u), Bfx);
+            const float tny = fmaf(Ay, float((qny >> (8 * i)) & 255u), Bny), tfy = fmaf(Ay, float((qfy >> (8 * i)) & 255u), Bfy);
+            const float tnz = fmaf(Az, float((qnz >> (8 * i)) & 255u), Bnz), tfz = fmaf(Az, float((qfz >> (8 * i)) & 255u), Bfz);
+            float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), 0.0f);
+            const float tf = fminf(fminf(tfx, tfy), tfz);
             tn = fmaf(-K, tn, tn); // a lower bound of the true entry distance
             const bool hit = (tn <= fmaf(K, fabsf(tf), tf)) & (tn <= tmaxf) & (child != 0xFFFFFFFFu);
             return hit ? (((__float_as_uint(tn) >> (id_bits - 1)) << id_bits) | child) : 0xFFFFFFFFu;
         };
-        uint32_t k0 = slab(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, q6.x);
-        uint32_t k1 = slab(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, q6.y);
-        uint32_t k2 = slab(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, q6.z);
-        uint32_t k3 = slab(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, q6.w);
+        uint32_t k0 = slab(0, n0.w);
+        uint32_t k1 = slab(1, n1.w);
+        uint32_t k2 = slab(2, n3.z);
+        uint32_t k3 = slab(3, n3.w);
         auto order = [](uint32_t &a, uint32_t &b) {
             const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
             a = lo, b = hi;
