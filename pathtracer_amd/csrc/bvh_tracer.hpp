@@ -132,9 +132,9 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             {
                 const int i = top - k;
                 const bool on = i >= 0 && i < len;
-#pragma unroll
-                for (int c = 0; c < 6; c++)
-                    q[k][c] = on ? rec[(on ? i : 0) * 6 + c] : R(0);
+q[k][0] = q[k][1] = q[k][2] = q[k][3] = q[k][4] = q[k][5] = R(0);
+                if (on) // lanes whose stack is shorter do not touch memory
+                    load_record(rec + i * 6, q[k]); // 48 (24) bytes in 3 loads
             }
 #pragma unroll
             for (int k = 0; k < G; k++)
@@ -212,11 +212,12 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                     const int face = S.tri_face[hit_k];
                     const float *__restrict__ vp = S.verts + (size_t)face * 9;
                     const float *__restrict__ np = S.normals + (size_t)face * 9;
-                    V3<R> a = {R(vp[0]), R(vp[1]), R(vp[2])}, b = {R(vp[3]), R(vp[4]), R(vp[5])}, c = {R(vp[6]), R(vp[7]), R(vp[8])};
+                    const Float9 fv = load9(vp), fq = load9(np);
+                    V3<R> a = {R(fv.v[0]), R(fv.v[1]), R(fv.v[2])}, b = {R(fv.v[3]), R(fv.v[4]), R(fv.v[5])}, c = {R(fv.v[6]), R(fv.v[7]), R(fv.v[8])};
                     V3<R> w = barycentric(p, a, b, c);
-                    V3<R> acc = w.x * V3<R>{R(np[0]), R(np[1]), R(np[2])};
-                    acc = acc + w.y * V3<R>{R(np[3]), R(np[4]), R(np[5])};
-                    acc = acc + w.z * V3<R>{R(np[6]), R(np[7]), R(np[8])};
+                    V3<R> acc = w.x * V3<R>{R(fq.v[0]), R(fq.v[1]), R(fq.v[2])};
+                    acc = acc + w.y * V3<R>{R(fq.v[3]), R(fq.v[4]), R(fq.v[5])};
+                    acc = acc + w.z * V3<R>{R(fq.v[6]), R(fq.v[7]), R(fq.v[8])};
                     nrm = fast_normalized(acc);
                 }
                 // ---- NEE over all lights (sphere lights only: the sampled segment is never tested) ---

@@ -698,6 +698,30 @@ __global__ void __launch_bounds__(BLOCK)
     vis[i] = visible<R, BRUTE>(S, a, b, stk) ? 1 : 0;
 }
 
+// nine consecutive floats (three vertices or vertex normals of a face; 4-byte aligned) in three loads
+struct __attribute__((packed, aligned(4))) Float9
+{
+    float v[9];
+};
+__device__ __forceinline__ Float9 load9(const float *p) { return *reinterpret_cast<const Float9 *>(p); }
+
+// one (direct rgb, coefficient rgb) record of a path's stack: 16-byte aligned in f64 (three 16-byte
+// loads), 8-byte aligned in f32 (three 8-byte loads)
+__device__ __forceinline__ void load_record(const double *rec, double *q)
+{
+    const uint4 *r = reinterpret_cast<const uint4 *>(rec);
+    const uint4 a = r[0], b = r[1], c = r[2];
+    q[0] = __hiloint2double(int(a.y), int(a.x)), q[1] = __hiloint2double(int(a.w), int(a.z));
+    q[2] = __hiloint2double(int(b.y), int(b.x)), q[3] = __hiloint2double(int(b.w), int(b.z));
+    q[4] = __hiloint2double(int(c.y), int(c.x)), q[5] = __hiloint2double(int(c.w), int(c.z));
+}
+__device__ __forceinline__ void load_record(const float *rec, float *q)
+{
+    const float2 *r = reinterpret_cast<const float2 *>(rec);
+    const float2 a = r[0], b = r[1], c = r[2];
+    q[0] = a.x, q[1] = a.y, q[2] = b.x, q[3] = b.y, q[4] = c.x, q[5] = c.y;
+}
+
 __device__ __forceinline__ int global_wave() { return int((blockIdx.x * BLOCK + threadIdx.x) >> 6); }
 __device__ __forceinline__ int lane_id() { return int(threadIdx.x & 63); }
 
@@ -909,9 +933,9 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             {
                 const int i = top - k;
                 const bool on = i >= 0 && i < len;
-#pragma unroll
-                for (int c = 0; c < 6; c++)
-                    q[k][c] = on ? rec[(on ? i : 0) * 6 + c] : R(0);
+q[k][0] = q[k][1] = q[k][2] = q[k][3] = q[k][4] = q[k][5] = R(0);
+                if (on) // lanes whose stack is shorter do not touch memory
+                    load_record(rec + i * 6, q[k]); // 48 (24) bytes in 3 loads
             }
 #pragma unroll
             for (int k = 0; k < G; k++)
@@ -1082,11 +1106,12 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 const int face = S.tri_face[hit_k];
                 const float *__restrict__ vp = S.verts + (size_t)face * 9;
                 const float *__restrict__ np = S.normals + (size_t)face * 9;
-                V3<R> a = {R(vp[0]), R(vp[1]), R(vp[2])}, b = {R(vp[3]), R(vp[4]), R(vp[5])}, c = {R(vp[6]), R(vp[7]), R(vp[8])};
+                const Float9 fv = load9(vp), fq = load9(np);
+                V3<R> a = {R(fv.v[0]), R(fv.v[1]), R(fv.v[2])}, b = {R(fv.v[3]), R(fv.v[4]), R(fv.v[5])}, c = {R(fv.v[6]), R(fv.v[7]), R(fv.v[8])};
                 V3<R> w = barycentric(p, a, b, c);
-                V3<R> acc = w.x * V3<R>{R(np[0]), R(np[1]), R(np[2])};
-                acc = acc + w.y * V3<R>{R(np[3]), R(np[4]), R(np[5])};
-                acc = acc + w.z * V3<R>{R(np[6]), R(np[7]), R(np[8])};
+                V3<R> acc = w.x * V3<R>{R(fq.v[0]), R(fq.v[1]), R(fq.v[2])};
+                acc = acc + w.y * V3<R>{R(fq.v[3]), R(fq.v[4]), R(fq.v[5])};
+                acc = acc + w.z * V3<R>{R(fq.v[6]), R(fq.v[7]), R(fq.v[8])};
                 nrm = fast_normalized(acc);
             }
 
