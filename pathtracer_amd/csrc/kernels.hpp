@@ -266,7 +266,7 @@ __device__ __forceinline__ unsigned long long drop_own_plane(unsigned long long 
 // side) and only ever make a box look nearer and longer: plane distances are computed as
 // (cell * slope) * coordinate + (corner - origin) * slope, near planes from the end of the origin
 // interval that makes them nearer and lowered by a bound of the roundings of that sum, far planes
-// the other way round, and entry distances are scaled down by another 2^-20.  So a box that holds
+// the other way round.  So a box that holds
 // a triangle whose exact distance could win or tie is never skipped, and hits, distances and ties
 // are those of testing every triangle exactly.
 //
@@ -402,13 +402,13 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
         const float tmaxf = float(T.best) * (1.0f + K) + 1e-30f;
         // plane distance t = A * q + B per axis, A = cell * slope, B = (corner - origin) * slope, with
         // the origin end and the plane (low or high) that make a near plane nearer and a far plane
-        // farther; the roundings of A, B and of the sum are bounded by 2^-21 (255 |A| + |B|), which
-        // is taken off the near planes and added to the far ones
+        // farther; the roundings of A, B and of the sum are bounded by 2^-21 (255 |A| + |B|); four
+        // times that is taken off the near planes and added to the far ones
         const float Ax = __uint_as_float(n1.x) * T.ivx, Ay = __uint_as_float(n1.y) * T.ivy, Az = __uint_as_float(n1.z) * T.ivz;
         float Bnx = (__uint_as_float(n0.x) - T.onx) * T.ivx, Bfx = (__uint_as_float(n0.x) - T.ofx) * T.ivx;
         float Bny = (__uint_as_float(n0.y) - T.ony) * T.ivy, Bfy = (__uint_as_float(n0.y) - T.ofy) * T.ivy;
         float Bnz = (__uint_as_float(n0.z) - T.onz) * T.ivz, Bfz = (__uint_as_float(n0.z) - T.ofz) * T.ivz;
-        constexpr float M = 0x1p-21f;
+        constexpr float M = 0x1p-19f;
         const float mx = M * (255.0f * fabsf(Ax) + fmaxf(fabsf(Bnx), fabsf(Bfx)));
         const float my = M * (255.0f * fabsf(Ay) + fmaxf(fabsf(Bny), fabsf(Bfy)));
         const float mz = M * (255.0f * fabsf(Az) + fmaxf(fabsf(Bnz), fabsf(Bfz)));
@@ -421,10 +421,10 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
             const float tnx = fmaf(Ax, float((qnx >> (8 * i)) & 255u), Bnx), tfx = fmaf(Ax, float((qfx >> (8 * i)) & 255u), Bfx);
             const float tny = fmaf(Ay, float((qny >> (8 * i)) & 255u), Bny), tfy = fmaf(Ay, float((qfy >> (8 * i)) & 255u), Bfy);
             const float tnz = fmaf(Az, float((qnz >> (8 * i)) & 255u), Bnz), tfz = fmaf(Az, float((qfz >> (8 * i)) & 255u), Bfz);
-            float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), 0.0f);
+            // tn: a lower bound of the true entry distance, tf: an upper bound of the exit distance
+            const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), 0.0f);
             const float tf = fminf(fminf(tfx, tfy), tfz);
-            tn = fmaf(-K, tn, tn); // a lower bound of the true entry distance
-            const bool hit = (tn <= fmaf(K, fabsf(tf), tf)) & (tn <= tmaxf) & (child != 0xFFFFFFFFu);
+            const bool hit = (tn <= tf) & (tn <= tmaxf) & (child != 0xFFFFFFFFu);
             return hit ? (((__float_as_uint(tn) >> (id_bits - 1)) << id_bits) | child) : 0xFFFFFFFFu;
         };
         uint32_t k0 = slab(0, n0.w);
