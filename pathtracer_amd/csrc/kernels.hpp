@@ -933,7 +933,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             {
                 const int i = top - k;
                 const bool on = i >= 0 && i < len;
-q[k][0] = q[k][1] = q[k][2] = q[k][3] = q[k][4] = q[k][5] = R(0);
+                q[k][0] = q[k][1] = q[k][2] = q[k][3] = q[k][4] = q[k][5] = R(0);
                 if (on) // lanes whose stack is shorter do not touch memory
                     load_record(rec + i * 6, q[k]); // 48 (24) bytes in 3 loads
             }
