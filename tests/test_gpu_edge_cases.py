@@ -169,3 +169,31 @@ def test_ring_tracer_without_lights_and_without_indirect_light(mis):
     img, st, oimg, ost, _ = render_both(ref)
     assert_f64_parity(img, oimg, st, ost)
     assert st["segments"] == st["paths"]                      # one segment per path: no continuation rays
+
+
+def test_ring_tracer_with_tables_too_large_for_lds(mis):
+    """More materials and more (sphere) lights than the LDS copies hold: the ring tracer reads both
+    tables from global memory; the material split alone must not change a bit."""
+    base, _, _, _, _ = render_both(mis)
+    ref = copy.deepcopy(mis)
+    n_m = len(ref.mats)
+    reps = 40 // n_m + 1
+    ref.mats = np.tile(ref.mats, (reps, 1))                     # copies of the table ...
+    ref.mat_ids = (ref.mat_ids + n_m * (np.arange(len(ref.mat_ids)) % reps)).astype(np.int32)  # ... used in turn
+    img, st, oimg, ost, _ = render_both(ref)
+    assert len(ref.mats) > 32
+    assert_f64_parity(img, oimg, st, ost)
+    assert np.array_equal(img, base)
+    rng = np.random.default_rng(5)
+    extra = []
+    for k in range(30):
+        L = np.zeros(ref.lights.shape[1])
+        L[0] = 1.0
+        L[1:4] = rng.uniform(0.05, 0.3, 3)
+        L[4:7] = ref.lights[k % len(ref.lights)][4:7] + rng.uniform(-1, 1, 3)
+        L[7] = rng.uniform(0.05, 0.2)
+        extra.append(L)
+    ref.lights = np.concatenate([ref.lights, np.array(extra)])
+    assert len(ref.lights) > 32
+    img, st, oimg, ost, _ = render_both(ref)
+    assert_f64_parity(img, oimg, st, ost)
