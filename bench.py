@@ -85,6 +85,10 @@ def main():
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--scheme", default="samples", choices=["samples", "bands"],
+                    help="multi-GPU sharding: 'samples' = every rank renders --spp samples of every pixel (weak "
+                         "scaling, the default), 'bands' = the ranks share the rows of one --spp frame in interleaved "
+                         "bands of 8 (strong scaling)")
     args = ap.parse_args()
 
     import torch
@@ -113,7 +117,7 @@ def main():
     ctx = pt.Context(local_rank, stream=stream.cuda_stream, batch_paths=args.batch_paths or None)
     ctx.build_accel(scene)
     out = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
-    spp_total = args.spp * world
+    spp_total = args.spp * world if args.scheme == "samples" else args.spp
 
     from pathtracer_amd.distributed import render_frame
 
@@ -121,8 +125,9 @@ def main():
         return ctx.render_device(o.data_ptr(), **kw)
 
     def step(profile=False, mode=None, reduce=True):
-        # rank r renders samples [r*spp, (r+1)*spp) of every pixel, then RCCL reduce(sum) -> rank 0
-        return render_frame(render_fn, out, spp_total, rank, world, scheme="samples", reduce=reduce,
+        # samples: rank r renders samples [r*spp, (r+1)*spp) of every pixel; bands: its rows of the
+        # frame (the rest of `out` stays zero); then RCCL reduce(sum) -> rank 0
+        return render_frame(render_fn, out, spp_total, rank, world, scheme=args.scheme, reduce=reduce,
                             mode=mode or args.mode, seed=13, profile=profile)
 
     def fence():
@@ -142,7 +147,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    paths_per_step = W * H * args.spp * world
+    paths_per_step = W * H * spp_total
     value = paths_per_step * args.steps / dt / 1e6
 
     result = None
@@ -153,7 +158,7 @@ def main():
         torch.cuda.synchronize()
         ms = {"trace": ps["ms_trace"], "accumulate": ps["ms_accumulate"]}
         passes = int(ps["passes"])
-        ab = algorithmic_bytes(args.mode, ps, W * H * passes)
+        ab = algorithmic_bytes(args.mode, ps, int(ps["paths"]) // args.spp * passes)  # pixels of this rank x launches
         dom = max(ms, key=ms.get)
         kernels = {}
         for k in ms:
@@ -212,14 +217,16 @@ def main():
         result = {
             "metric": "Mpaths/s at %s %dx%d (whole job, all GPUs)" % (scene_name, W, H), "value": round(value, 3), "unit": "Mpaths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak" if args.scheme == "samples" else "strong",
             "vs_baseline": None, "dtype": args.mode, "data": "synthetic",
             "config": {"workload": "%s %dx%d, %d spp per GPU, depth %d, %d triangles, %d lights (%d square) (%s%s)"
                                    % (scene_name, W, H, args.spp, info.depth, info.n_tris, info.n_lights, info.n_square_lights,
                                       args.conf, ", the headline configuration" if headline else ""),
                        "intersector": "all-triangles (plane records)" if ctx.accel_info()["brute_force"] else "BVH",
                        "global_spp": spp_total, "paths_per_step": paths_per_step,
-                       "sharding": "sample ranges per rank + RCCL reduce(sum) of the radiance sums to rank 0"},
+                       "sharding": ("sample ranges per rank" if args.scheme == "samples" else "interleaved row bands of 8 per rank")
+                                   + " + RCCL reduce(sum) of the radiance sums to rank 0"},
             "mrays_per_s": round((st["segments"] + st["shadow_rays"]) * world * args.steps / dt / 1e6, 1),
             "segments_per_path": round(st["segments"] / st["paths"], 3),
             "roofline": roofline, "valu": valu, "kernels": kernels, "kernel_ms_per_step": kernel_ms,
