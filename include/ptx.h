@@ -143,7 +143,7 @@ void ptx_context_destroy(ptx_context *);
  * the occupancy calculator reports), "shadow_queue" (1/0: park the visibility tests of
  * one-square-light scenes in the per-wave LDS queue, or run them in place), "lds_stack_levels"
  * (BVH scenes: at most this many traversal stack levels per lane in LDS, deeper ones in a global
- * array; 0 = as many as fit at full occupancy), "bvh_rings" (1/0: BVH scenes without square lights are
+ * array; 0 = as many as fit at full occupancy), "bvh_rings" (1/0: BVH scenes with at most one square light are
  * traced with per-wave hit and ray rings -- more paths in flight than lanes, shading on full waves
  * -- or with one path per lane).  Results do not depend on any of them.  Set before
  * ptx_build_accel. */

@@ -1,5 +1,5 @@
-// Tracer of BVH scenes without square lights (no visibility tests): a wave keeps more paths in
-// flight than it has lanes.  Included by kernels.hpp.
+// Tracer of BVH scenes with at most one square light (at most one visibility test per bounce): a
+// wave keeps more paths in flight than it has lanes.  Included by kernels.hpp.
 //
 // With the BVH, the 64 lanes of a wave are at three different kinds of work -- node tests, exact
 // triangle tests, shading -- and whatever runs, runs on the lanes that happen to be there.  Here the
@@ -14,6 +14,14 @@
 // not between two rays; every path is in exactly one place (a lane, the ray ring or the hit ring),
 // camera rays are only admitted while fewer than 128 paths are in flight, so neither ring
 // (256 entries) can overflow, and the wave ends when the pool is used up and all three are empty.
+//
+// SQ (the scene has exactly one square light): a bounce whose light sample is valid needs the
+// reference's visibility test before its record can be written.  The shading pass then does not
+// finish the hit: it sends it back through the ray ring as a SHADOW entry (same fields as a hit);
+// the lane that takes it recomputes the light sample point from the path's random numbers, runs
+// the any-hit traversal from the light to the shaded point, and hands the hit back to the hit ring
+// marked visible or blocked; the second shading pass finishes it.  The path is still in exactly
+// one place at any time, and no record is ever patched after the fact.
 #pragma once
 
 namespace ptx
@@ -21,22 +29,26 @@ namespace ptx
 
 constexpr int RING_CAP = 256;       // entries of either ring
 constexpr int RING_ADMIT = 128;     // camera rays are admitted while at most this many paths are in flight
+constexpr uint32_t RING_SHADOW = 1u << 30;                         // ray ring: a visibility test, not a ray
+constexpr uint32_t RING_VISIBLE = 1u << 30, RING_BLOCKED = 2u << 30; // hit ring: result of that test
+constexpr uint32_t RING_BOUNCE = (1u << 30) - 1u;
 constexpr int RING_BATCH = 40;      // lanes that hand over hits / take rays together (a hand-over drains the
                                     // wave's outstanding loads; measured plateau: 32 to 48)
 
 // bytes of one wave's two rings
-template <class R> constexpr size_t ring_bytes() { return size_t(RING_CAP) * (12 * sizeof(R) + 4 * 9); }
+template <class R> constexpr size_t ring_bytes() { return size_t(RING_CAP) * (12 * sizeof(R) + 4 * 10); }
 
 // views of the two rings of one wave (structure of arrays: one field of 256 entries after the other)
 template <class R> struct Rings
 {
     // ray ring
     R *ro, *rd;        // [3][CAP] each
-    uint32_t *r_pid, *r_bounce, *r_klo, *r_khi;
+    uint32_t *r_pid, *r_bounce, *r_klo, *r_khi; // r_bounce: bounce | RING_SHADOW
+    int32_t *r_tri;    // shadow entries: the triangle the shaded point lies on
     // hit ring
     R *hp, *hd;        // [3][CAP]: hit point, ray direction
     int32_t *h_tri;
-    uint32_t *h_pid, *h_bounce, *h_klo, *h_khi;
+    uint32_t *h_pid, *h_bounce, *h_klo, *h_khi; // h_bounce: bounce | RING_VISIBLE / RING_BLOCKED once tested
     __device__ explicit Rings(void *base)
     {
         R *f = reinterpret_cast<R *>(base);
@@ -45,6 +57,7 @@ template <class R> struct Rings
         r_pid = u, r_bounce = u + RING_CAP, r_klo = u + 2 * RING_CAP, r_khi = u + 3 * RING_CAP;
         h_tri = reinterpret_cast<int32_t *>(u + 4 * RING_CAP);
         h_pid = u + 5 * RING_CAP, h_bounce = u + 6 * RING_CAP, h_klo = u + 7 * RING_CAP, h_khi = u + 8 * RING_CAP;
+        r_tri = reinterpret_cast<int32_t *>(u + 9 * RING_CAP);
     }
 };
 
@@ -63,7 +76,7 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
 }
 
-template <class R, bool TAB>
+template <class R, bool TAB, bool SQ>
 __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCamera &cam, const DBatch &B, const DState<R> &st, int chunk)
 {
     __shared__ R lds_mats[TAB ? LDS_MATS * MAT_STRIDE : 1];
@@ -98,7 +111,10 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     trav_init(T, V3<R>{R(0), R(0), R(0)}, V3<R>{R(1), R(1), R(1)});
     V3<R> o = {R(0), R(0), R(0)}, d = {R(0), R(0), R(0)};
     uint32_t pid = 0, bounce = 0, klo = 0, khi = 0;
-    uint32_t n_seg = 0, n_iter = 0, n_rec = 0;
+    // a visibility test in flight: the hit it belongs to (handed back when the test is done)
+    V3<R> vp = {R(0), R(0), R(0)}, vd = {R(0), R(0), R(0)};
+    int vtri = -1;
+    uint32_t n_seg = 0, n_iter = 0, n_rec = 0, n_tests = 0;
     uint32_t n_visit[2] = {0, 0};
 
     // folds 64 (or the last n) finished paths back to front, one per lane
@@ -172,17 +188,22 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
         n_iter++;
         const uint32_t e = (hq_head + uint32_t(lane)) % RING_CAP;
         const bool mine = uint32_t(lane) < n;
-        bool finished = false, cont = false;
+        bool finished = false, cont = false, defer = false;
         uint32_t fin_state = 0;
-        V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
+        V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)}, keep_d = {R(0), R(0), R(0)};
         uint32_t s_pid = 0, s_bounce = 0, s_klo = 0, s_khi = 0;
+        int keep_tri = -1;
         if (mine)
         {
-            n_seg++;
             p = {Q.hp[e], Q.hp[RING_CAP + e], Q.hp[2 * RING_CAP + e]};
             const V3<R> sd = {Q.hd[e], Q.hd[RING_CAP + e], Q.hd[2 * RING_CAP + e]};
             const int hit_k = Q.h_tri[e];
             s_pid = Q.h_pid[e], s_bounce = Q.h_bounce[e], s_klo = Q.h_klo[e], s_khi = Q.h_khi[e];
+            const uint32_t vis = s_bounce & ~RING_BOUNCE; // 0: not tested (yet), else RING_VISIBLE / RING_BLOCKED
+            s_bounce &= RING_BOUNCE;
+            keep_d = sd, keep_tri = hit_k;
+            if (vis == 0u)
+                n_seg++;
             const uint64_t key = (uint64_t(s_khi) << 32) | s_klo;
             const uint32_t sample = uint32_t(B.sample0) + s_pid / n_pix;
             const int bnc = int(s_bounce);
@@ -220,7 +241,8 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                     acc = acc + w.z * V3<R>{R(fq.v[6]), R(fq.v[7]), R(fq.v[8])};
                     nrm = fast_normalized(acc);
                 }
-                // ---- NEE over all lights (sphere lights only: the sampled segment is never tested) ---
+                // ---- NEE over all lights, in order.  Sphere-light segments are never tested; the square
+                // light's is: a fresh hit with a valid sample goes back out as a visibility test -----------
                 V3<R> direct = {R(0), R(0), R(0)};
                 for (int l = 0; l < S.n_lights; l++)
                 {
@@ -232,45 +254,70 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                     V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
                     const R x1 = rng_draw<R>(key, sample, bnc, 4 * l + 0);
                     const R x2 = rng_draw<R>(key, sample, bnc, 4 * l + 1);
-                    const R pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bnc, 4 * l + 2), ro, rd);
+                    const bool square = SQ && l == S.sq_light;
+                    R pdf;
+                    if (square)
+                        pdf = square_light_sample(L, p, x1, x2, ro, rd);
+                    else
+                        pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bnc, 4 * l + 2), ro, rd);
                     if (pdf < R(1e-10))
                         continue;
                     const R cn = dot(nrm, -rd);
                     if (cn < R(0))
                         continue;
+                    if (square)
+                    {
+                        if (vis == 0u)
+                        {
+                            defer = true;
+                            break;
+                        }
+                        if (vis == RING_BLOCKED)
+                            continue;
+                    }
                     const V3<R> f = bxdf_eval(m, rd, wo, nrm);
                     const R w = cn / pdf;
                     direct = direct + V3<R>{(L[1] * w) * f.x, (L[2] * w) * f.y, (L[3] * w) * f.z};
                 }
-                // ---- next direction and indirect coefficient -----------------------------------------
-                V3<R> coef = {R(0), R(0), R(0)};
-                if (S.enable_indirect)
+                if (!defer)
                 {
-                    const R x1 = rng_draw<R>(key, sample, bnc, 4 * S.n_lights + 0);
-                    const R x2 = rng_draw<R>(key, sample, bnc, 4 * S.n_lights + 1);
-                    bxdf_sample(m, nrm, wo, x1, x2, wi, coef);
+                    // ---- next direction and indirect coefficient -----------------------------------------
+                    V3<R> coef = {R(0), R(0), R(0)};
+                    if (S.enable_indirect)
+                    {
+                        const R x1 = rng_draw<R>(key, sample, bnc, 4 * S.n_lights + 0);
+                        const R x2 = rng_draw<R>(key, sample, bnc, 4 * S.n_lights + 1);
+                        bxdf_sample(m, nrm, wo, x1, x2, wi, coef);
+                    }
+                    R *rec = st.stack + ((size_t)s_pid * depth + bnc) * 6;
+                    rec[0] = direct.x, rec[1] = direct.y, rec[2] = direct.z;
+                    rec[3] = coef.x, rec[4] = coef.y, rec[5] = coef.z;
+                    n_rec++;
+                    if (S.enable_indirect && bnc + 1 < depth)
+                        cont = true;
+                    else
+                        finished = true, fin_state = uint32_t(bnc + 1) << 16;
                 }
-                R *rec = st.stack + ((size_t)s_pid * depth + bnc) * 6;
-                rec[0] = direct.x, rec[1] = direct.y, rec[2] = direct.z;
-                rec[3] = coef.x, rec[4] = coef.y, rec[5] = coef.z;
-                n_rec++;
-                if (S.enable_indirect && bnc + 1 < depth)
-                    cont = true;
                 else
-                    finished = true, fin_state = uint32_t(bnc + 1) << 16;
+                    n_tests++;
             }
         }
         hq_head = (hq_head + n) % RING_CAP;
         hq_count -= n;
         // continuation rays -> ray ring
         {
-            const unsigned long long cm = __ballot(cont);
-            if (cont)
+            // (a lane has a continuation ray, or a visibility test, or neither)
+            const unsigned long long cm = __ballot(cont || defer);
+            if (cont || defer)
             {
                 const uint32_t r = (rq_head + rq_count + rank_in(cm)) % RING_CAP;
+                const V3<R> od = defer ? keep_d : wi;
                 Q.ro[r] = p.x, Q.ro[RING_CAP + r] = p.y, Q.ro[2 * RING_CAP + r] = p.z;
-                Q.rd[r] = wi.x, Q.rd[RING_CAP + r] = wi.y, Q.rd[2 * RING_CAP + r] = wi.z;
-                Q.r_pid[r] = s_pid, Q.r_bounce[r] = s_bounce + 1u, Q.r_klo[r] = s_klo, Q.r_khi[r] = s_khi;
+                Q.rd[r] = od.x, Q.rd[RING_CAP + r] = od.y, Q.rd[2 * RING_CAP + r] = od.z;
+                Q.r_pid[r] = s_pid, Q.r_bounce[r] = defer ? (s_bounce | RING_SHADOW) : s_bounce + 1u;
+                Q.r_klo[r] = s_klo, Q.r_khi[r] = s_khi;
+                if (SQ)
+                    Q.r_tri[r] = keep_tri;
             }
             rq_count += uint32_t(__popcll(cm));
         }
@@ -307,10 +354,10 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             if (n_tri * 2 > (n_trav - n_tri) * 3)
             {
                 if (at_tri)
-                    done = !bvh_step<R, false, 2>(S, o, d, T, stk, n_visit);
+                    done = !bvh_step<R, SQ ? 2 : 0, 2>(S, o, d, T, stk, n_visit);
             }
             else if (act && !at_tri)
-                done = !bvh_step<R, false, 1>(S, o, d, T, stk, n_visit);
+                done = !bvh_step<R, SQ ? 2 : 0, 1>(S, o, d, T, stk, n_visit);
         }
         // ---- completed traversals -> hit ring -----------------------------------------------------
         if (n_done >= RING_BATCH || (n_done > 0 && n_busy == n_done))
@@ -320,11 +367,14 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             if (give)
             {
                 const uint32_t r = (hq_head + hq_count + rank_in(gm)) % RING_CAP;
-                const V3<R> p = o + T.best_t * d;
+                const bool test = SQ && T.any != 0; // a finished visibility test hands its hit back, marked
+                const V3<R> p = test ? vp : o + T.best_t * d;
+                const V3<R> hd = test ? vd : d;
                 Q.hp[r] = p.x, Q.hp[RING_CAP + r] = p.y, Q.hp[2 * RING_CAP + r] = p.z;
-                Q.hd[r] = d.x, Q.hd[RING_CAP + r] = d.y, Q.hd[2 * RING_CAP + r] = d.z;
-                Q.h_tri[r] = T.target;
-                Q.h_pid[r] = pid, Q.h_bounce[r] = bounce, Q.h_klo[r] = klo, Q.h_khi[r] = khi;
+                Q.hd[r] = hd.x, Q.hd[RING_CAP + r] = hd.y, Q.hd[2 * RING_CAP + r] = hd.z;
+                Q.h_tri[r] = test ? vtri : T.target;
+                Q.h_pid[r] = pid, Q.h_klo[r] = klo, Q.h_khi[r] = khi;
+                Q.h_bounce[r] = test ? (bounce | (T.target == 1 ? RING_BLOCKED : RING_VISIBLE)) : bounce;
                 busy = false, done = false;
             }
             hq_count += uint32_t(__popcll(gm));
@@ -379,7 +429,30 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 o = {Q.ro[r], Q.ro[RING_CAP + r], Q.ro[2 * RING_CAP + r]};
                 d = {Q.rd[r], Q.rd[RING_CAP + r], Q.rd[2 * RING_CAP + r]};
                 pid = Q.r_pid[r], bounce = Q.r_bounce[r], klo = Q.r_klo[r], khi = Q.r_khi[r];
-                trav_init(T, o, d);
+                if (SQ && (bounce & RING_SHADOW))
+                {
+                    // a visibility test: the entry is the hit (point, incoming direction, triangle); the
+                    // segment runs from the light sample point, a function of the path's random numbers,
+                    // to the shaded point, as in visible()
+                    bounce &= RING_BOUNCE;
+                    vp = o, vd = d, vtri = Q.r_tri[r];
+                    const R *L;
+                    if constexpr (TAB)
+                        L = lds_lights + S.sq_light * LIGHT_STRIDE;
+                    else
+                        L = S.lights + (size_t)S.sq_light * LIGHT_STRIDE;
+                    const uint64_t key = (uint64_t(khi) << 32) | klo;
+                    const uint32_t sample = uint32_t(B.sample0) + pid / n_pix;
+                    const R x1 = rng_draw<R>(key, sample, bounce, 4 * S.sq_light + 0);
+                    const R x2 = rng_draw<R>(key, sample, bounce, 4 * S.sq_light + 1);
+                    const V3<R> s = square_light_point(L, x1, x2);
+                    const R dist = norm(s - vp);
+                    o = s, d = normalized(vp - s);
+                    trav_init(T, o, d, dist);
+                    T.any = 1;
+                }
+                else
+                    trav_init(T, o, d);
                 busy = true, done = false;
             }
             const uint32_t taken = min(uint32_t(__popcll(fm)), rq_count);
@@ -393,14 +466,14 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     while (dq_count > 0u)
         resolve(dq_count < 64u ? dq_count : 64u);
     // per-wave statistics (the wave owns its row)
-    unsigned long long tot[5] = {n_seg, n_rec, n_visit[0], n_visit[1], 0};
+    unsigned long long tot[5] = {n_seg, n_rec, n_visit[0], n_visit[1], n_tests};
     for (int off = 32; off > 0; off >>= 1)
-        for (int c = 0; c < 4; c++)
+        for (int c = 0; c < 5; c++)
             tot[c] += __shfl_down(tot[c], off, 64);
     if (lane == 0)
     {
         st.wave_stats[g * WAVE_STATS + 0] = tot[0];
-        st.wave_stats[g * WAVE_STATS + 1] = 0;
+        st.wave_stats[g * WAVE_STATS + 1] = tot[4];
         st.wave_stats[g * WAVE_STATS + 2] = n_iter;
         st.wave_stats[g * WAVE_STATS + 3] = tot[1];
         st.wave_stats[g * WAVE_STATS + 4] = tot[2];
@@ -408,15 +481,15 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     }
 }
 
-template <bool TAB>
+template <bool TAB, bool SQ>
 __global__ void __launch_bounds__(BLOCK, 3) k_trace_rings_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
 {
-    trace_body_rings<double, TAB>(S, cam, B, st, chunk);
+    trace_body_rings<double, TAB, SQ>(S, cam, B, st, chunk);
 }
-template <bool TAB>
-__global__ void __launch_bounds__(BLOCK, 4) k_trace_rings_f32(DScene<float> S, DCamera cam, DBatch B, DState<float> st, int chunk)
+template <bool TAB, bool SQ>
+__global__ void __launch_bounds__(BLOCK, SQ ? 3 : 4) k_trace_rings_f32(DScene<float> S, DCamera cam, DBatch B, DState<float> st, int chunk)
 {
-    trace_body_rings<float, TAB>(S, cam, B, st, chunk);
+    trace_body_rings<float, TAB, SQ>(S, cam, B, st, chunk);
 }
 
 } // namespace ptx

@@ -482,6 +482,10 @@ template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::
     S.bvh_tris = static_cast<const uint4 *>(bvh);
     S.n_nodes = g.n_nodes, S.id_bits = g.id_bits;
     S.stack_levels = g.stack_need; // the operator kernels keep the whole stack in LDS
+    S.sq_light = -1, S.pad3_ = 0;
+    for (size_t l = 0; l < sc.lights.size() && S.sq_light < 0; l++)
+        if (sc.lights[l].type == 0)
+            S.sq_light = static_cast<int>(l);
     S.spill_stride = 0;
     S.spill = nullptr;
     return S;
@@ -641,14 +645,17 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
         pick(std::true_type());
     else
         pick(std::false_type());
-    if (!BRUTE && lights == 0 && rings)
+    if (!BRUTE && S.n_square <= 1 && rings)
     {
-        // no visibility tests at all: the tracer that keeps more paths in flight than lanes
+        // at most one visibility test per bounce: the tracer that keeps more paths in flight than lanes
         p.rings = true;
+        const bool sq = S.n_square == 1;
         if constexpr (sizeof(R) == 8)
-            p.kernel = tab ? k_trace_rings_f64<true> : k_trace_rings_f64<false>;
+            p.kernel = tab ? (sq ? k_trace_rings_f64<true, true> : k_trace_rings_f64<true, false>)
+                           : (sq ? k_trace_rings_f64<false, true> : k_trace_rings_f64<false, false>);
         else
-            p.kernel = tab ? k_trace_rings_f32<true> : k_trace_rings_f32<false>;
+            p.kernel = tab ? (sq ? k_trace_rings_f32<true, true> : k_trace_rings_f32<true, false>)
+                           : (sq ? k_trace_rings_f32<false, true> : k_trace_rings_f32<false, false>);
     }
     // BVH kernels: how many stack levels to keep in LDS.  The registers (and the static LDS)
     // allow `by_regs` workgroups per CU; the stacks get what is left of the CU's LDS at that

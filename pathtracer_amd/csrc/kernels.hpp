@@ -50,6 +50,7 @@ template <class R> struct DScene
     const uint4 *bvh_nodes;    // [n_nodes][4] 64-byte nodes of the 4-wide BVH (child boxes quantised to 8 bits)
     const uint4 *bvh_tris;     // [n_tris][5 (f64) or 3 (f32)] triangle records in intersector order: p1, p1-p2, p1-p3, face id
     int n_nodes, id_bits;      // id_bits: bits of a stack entry that hold the record id
+    int sq_light, pad3_;       // index of the first square light (-1: none)
     int stack_levels;          // traversal stack levels held in LDS; deeper levels go to `spill`
     int spill_stride;          // lanes of the launch
     uint32_t *spill;           // [levels beyond stack_levels][spill_stride] (null when the LDS stack holds the whole bound)
@@ -278,6 +279,7 @@ template <class R> struct Trav
 {
     int cur;      // record to visit next (< S.n_nodes: node, else triangle cur - S.n_nodes)
     int sp, target, best_face;
+    int any;      // ANY == 2 only: this lane's traversal is an any-hit (visibility) one
     R best;       // closest accepted distance so far (any-hit: length of the segment)
     R best_t;     // ray parameter of that hit: the hit point is o + best_t * d
     float onx, ony, onz, ofx, ofy, ofz; // end of the origin interval that makes the near / far plane of a slab nearer / farther
@@ -286,6 +288,7 @@ template <class R> struct Trav
 template <class R> __device__ __forceinline__ void trav_init(Trav<R> &T, V3<R> o, V3<R> d, R limit = Consts<R>::big)
 {
     T.cur = 0, T.sp = 0, T.target = -1, T.best_face = 0x7fffffff;
+    T.any = 0;
     T.best = limit;
     T.best_t = R(0);
     const float fx = float(o.x), fy = float(o.y), fz = float(o.z);
@@ -352,11 +355,11 @@ typedef __attribute__((address_space(1))) uint32_t global_u32_t;
 
 // One record visit.  ANY = false: closest hit (winner = smallest distance beyond self_eps, ties ->
 // lowest face id; T.target = triangle, o + T.best_t * d = point).  ANY = true: is the segment of length T.best
-// blocked (T.target = 1 and the traversal ends at the first blocker).  The lane's stack is
+// blocked (T.target = 1 and the traversal ends at the first blocker).  ANY = 2: which of the two, per lane (T.any).  The lane's stack is
 // stk[level * BLOCK] in LDS.  Returns false once the traversal is complete.
 // KIND = 1 / 2: the caller has established that the lane is at a node / a triangle record (the
 // tracer advances the two kinds in separate wave steps so that neither runs on half-empty lanes).
-template <class R, bool ANY, int KIND = 0>
+template <class R, int ANY, int KIND = 0>
 __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, Trav<R> &T, int *stk, uint32_t *visits)
 {
     constexpr float K = 0x1p-20f;
@@ -370,7 +373,7 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
         const int face = load_tri(S.bvh_tris + (size_t)(T.cur - S.n_nodes) * tri_rec_q<R>(), tri);
         if (tri_test(tri, o, d, t))
         {
-            if (ANY)
+            if (ANY == 1 || (ANY == 2 && T.any))
             {
                 if (t < T.best - self_eps && t > self_eps)
                 {

@@ -261,15 +261,18 @@ def test_bvh_stack_spill_is_bit_invariant(root, conf, kw):
 
 
 @pytest.mark.parametrize("conf,kw", [("config/mis.conf", dict(width=160, height=96, spp=8)),
-                                     ("config/room.conf", dict(width=96, height=64, spp=3))])
+                                     ("config/room.conf", dict(width=96, height=64, spp=3)),
+                                     ("config/cbox.conf", dict(width=96, height=96, spp=6))])
 def test_ring_tracer_equals_lane_tracer(root, conf, kw):
-    """BVH scenes without square lights: the tracer that queues hits and rays per wave (more paths in
-    flight than lanes) and the one that keeps every path on its lane render the same bits and
-    visit the same BVH records, whatever the grid and the LDS share of the stacks."""
+    """BVH scenes with at most one square light (the Cornell box forced onto the BVH: its visibility
+    tests travel through the rings too): the tracer that queues hits and rays per wave (more paths
+    in flight than lanes) and the one that keeps every path on its lane render the same bits, run
+    the same visibility tests and visit the same BVH records, whatever the grid and the LDS share of
+    the stacks."""
     s, ref = load(root, conf, **kw)
     out = {}
     for rings, extra in ((0, {}), (1, {}), (1, dict(trace_blocks_per_cu=1, lds_stack_levels=4)), (1, dict(chunk_paths=4096))):
-        c = pt.Context(0)
+        c = pt.Context(0, brute_force_limit=0)
         c.set_option("bvh_rings", rings)
         for k, v in extra.items():
             c.set_option(k, v)
@@ -279,7 +282,7 @@ def test_ring_tracer_equals_lane_tracer(root, conf, kw):
             img, st = c.render(mode=mode)
             if mode in out:
                 assert np.array_equal(img, out[mode][0]), (rings, extra, mode)
-                for k in ("segments", "records", "bvh_nodes", "bvh_tris", "paths"):
+                for k in ("segments", "records", "shadow_rays", "bvh_nodes", "bvh_tris", "paths"):
                     assert st[k] == out[mode][1][k], (k, rings, extra, mode)
             else:
                 out[mode] = (img, st)
