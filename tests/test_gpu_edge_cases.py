@@ -197,3 +197,21 @@ def test_ring_tracer_with_tables_too_large_for_lds(mis):
     assert len(ref.lights) > 32
     img, st, oimg, ost, _ = render_both(ref)
     assert_f64_parity(img, oimg, st, ost)
+
+
+@pytest.mark.parametrize("position", [0, 3])
+def test_ring_tracer_with_one_square_light_among_sphere_lights(mis, position):
+    """The square light's visibility tests go round the rings; the light sum keeps the light order
+    whether the square light comes first or in the middle."""
+    ref = copy.deepcopy(mis)
+    lo, hi = ref.verts.reshape(-1, 3).min(0), ref.verts.reshape(-1, 3).max(0)
+    c, e, y = 0.5 * (lo + hi), 0.2 * (hi - lo), hi[1] - 0.05 * (hi[1] - lo[1])
+    L = np.zeros(ref.lights.shape[1])
+    L[1:4] = 5.0
+    L[4:16] = np.array([[c[0] - e[0], y, c[2] - e[2]], [c[0] + e[0], y, c[2] - e[2]],
+                        [c[0] + e[0], y, c[2] + e[2]], [c[0] - e[0], y, c[2] + e[2]]]).ravel()
+    ref.lights = np.insert(ref.lights, position, L, axis=0)
+    img, st, oimg, ost, c_ = render_both(ref)
+    assert not c_.accel_info()["brute_force"]
+    assert st["shadow_rays"] > 0
+    assert_f64_parity(img, oimg, st, ost)
