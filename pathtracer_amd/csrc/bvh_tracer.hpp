@@ -487,7 +487,7 @@ __global__ void __launch_bounds__(BLOCK, 3) k_trace_rings_f64(DScene<double> S, 
     trace_body_rings<double, TAB, SQ>(S, cam, B, st, chunk);
 }
 template <bool TAB, bool SQ>
-__global__ void __launch_bounds__(BLOCK, SQ ? 3 : 4) k_trace_rings_f32(DScene<float> S, DCamera cam, DBatch B, DState<float> st, int chunk)
+__global__ void __launch_bounds__(BLOCK, 4) k_trace_rings_f32(DScene<float> S, DCamera cam, DBatch B, DState<float> st, int chunk)
 {
     trace_body_rings<float, TAB, SQ>(S, cam, B, st, chunk);
 }
