@@ -1,5 +1,4 @@
-// Tracer of BVH scenes with at most one square light (at most one visibility test per bounce): a
-// wave keeps more paths in flight than it has lanes.  Included by kernels.hpp.
+// Tracer of BVH scenes (up to 12 square lights): a wave keeps more paths in flight than it has lanes.  Included by kernels.hpp.
 //
 // With the BVH, the 64 lanes of a wave are at three different kinds of work -- node tests, exact
 // triangle tests, shading -- and whatever runs, runs on the lanes that happen to be there.  Here the
@@ -15,13 +14,14 @@
 // camera rays are only admitted while fewer than 128 paths are in flight, so neither ring
 // (256 entries) can overflow, and the wave ends when the pool is used up and all three are empty.
 //
-// SQ (the scene has exactly one square light): a bounce whose light sample is valid needs the
-// reference's visibility test before its record can be written.  The shading pass then does not
+// SQ (the scene has square lights, at most 12): a bounce needs the reference's visibility test for
+// every square light whose sample is valid before its record can be written.  The shading pass then does not
 // finish the hit: it sends it back through the ray ring as a SHADOW entry (same fields as a hit);
 // the lane that takes it recomputes the light sample point from the path's random numbers, runs
 // the any-hit traversal from the light to the shaded point, and hands the hit back to the hit ring
-// marked visible or blocked; the second shading pass finishes it.  The path is still in exactly
-// one place at any time, and no record is ever patched after the fact.
+// with the result added to its state word; the next shading pass sends it out for the next test or
+// finishes it.  The path is still in exactly one place at any time, and no record is ever patched
+// after the fact.
 #pragma once
 
 namespace ptx
@@ -29,26 +29,28 @@ namespace ptx
 
 constexpr int RING_CAP = 256;       // entries of either ring
 constexpr int RING_ADMIT = 128;     // camera rays are admitted while at most this many paths are in flight
-constexpr uint32_t RING_SHADOW = 1u << 30;                         // ray ring: a visibility test, not a ray
-constexpr uint32_t RING_VISIBLE = 1u << 30, RING_BLOCKED = 2u << 30; // hit ring: result of that test
-constexpr uint32_t RING_BOUNCE = (1u << 30) - 1u;
+// state word of a ring entry: bounce in the low 16 bits, then how many visibility tests of this
+// bounce are done (4 bits) and their results (bit 20 + k: test k found a blocker)
+constexpr uint32_t RING_BOUNCE = 0xFFFFu;
+constexpr int RING_TESTS_SHIFT = 16, RING_RESULT_SHIFT = 20, RING_MAX_TESTS = 12;
 constexpr int RING_BATCH = 40;      // lanes that hand over hits / take rays together (a hand-over drains the
                                     // wave's outstanding loads; measured plateau: 32 to 48)
 
 // bytes of one wave's two rings
-template <class R> constexpr size_t ring_bytes() { return size_t(RING_CAP) * (12 * sizeof(R) + 4 * 10); }
+template <class R> constexpr size_t ring_bytes() { return size_t(RING_CAP) * (12 * sizeof(R) + 4 * 11); }
 
 // views of the two rings of one wave (structure of arrays: one field of 256 entries after the other)
 template <class R> struct Rings
 {
     // ray ring
     R *ro, *rd;        // [3][CAP] each
-    uint32_t *r_pid, *r_bounce, *r_klo, *r_khi; // r_bounce: bounce | RING_SHADOW
+    uint32_t *r_pid, *r_bounce, *r_klo, *r_khi; // r_bounce: state word
     int32_t *r_tri;    // shadow entries: the triangle the shaded point lies on
+    int32_t *r_light;  // -1: a ray; else a visibility test (shadow entry) against this light
     // hit ring
     R *hp, *hd;        // [3][CAP]: hit point, ray direction
     int32_t *h_tri;
-    uint32_t *h_pid, *h_bounce, *h_klo, *h_khi; // h_bounce: bounce | RING_VISIBLE / RING_BLOCKED once tested
+    uint32_t *h_pid, *h_bounce, *h_klo, *h_khi; // h_bounce: state word
     __device__ explicit Rings(void *base)
     {
         R *f = reinterpret_cast<R *>(base);
@@ -58,6 +60,7 @@ template <class R> struct Rings
         h_tri = reinterpret_cast<int32_t *>(u + 4 * RING_CAP);
         h_pid = u + 5 * RING_CAP, h_bounce = u + 6 * RING_CAP, h_klo = u + 7 * RING_CAP, h_khi = u + 8 * RING_CAP;
         r_tri = reinterpret_cast<int32_t *>(u + 9 * RING_CAP);
+        r_light = reinterpret_cast<int32_t *>(u + 10 * RING_CAP);
     }
 };
 
@@ -189,6 +192,8 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
         const uint32_t e = (hq_head + uint32_t(lane)) % RING_CAP;
         const bool mine = uint32_t(lane) < n;
         bool finished = false, cont = false, defer = false;
+        int defer_light = -1;
+        uint32_t defer_state = 0;
         uint32_t fin_state = 0;
         V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)}, keep_d = {R(0), R(0), R(0)};
         uint32_t s_pid = 0, s_bounce = 0, s_klo = 0, s_khi = 0;
@@ -199,10 +204,11 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             const V3<R> sd = {Q.hd[e], Q.hd[RING_CAP + e], Q.hd[2 * RING_CAP + e]};
             const int hit_k = Q.h_tri[e];
             s_pid = Q.h_pid[e], s_bounce = Q.h_bounce[e], s_klo = Q.h_klo[e], s_khi = Q.h_khi[e];
-            const uint32_t vis = s_bounce & ~RING_BOUNCE; // 0: not tested (yet), else RING_VISIBLE / RING_BLOCKED
+            const uint32_t state = s_bounce;
+            const int tested = int((state >> RING_TESTS_SHIFT) & 15u); // visibility tests of this bounce already done
             s_bounce &= RING_BOUNCE;
             keep_d = sd, keep_tri = hit_k;
-            if (vis == 0u)
+            if (tested == 0)
                 n_seg++;
             const uint64_t key = (uint64_t(s_khi) << 32) | s_klo;
             const uint32_t sample = uint32_t(B.sample0) + s_pid / n_pix;
@@ -244,6 +250,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 // ---- NEE over all lights, in order.  Sphere-light segments are never tested; the square
                 // light's is: a fresh hit with a valid sample goes back out as a visibility test -----------
                 V3<R> direct = {R(0), R(0), R(0)};
+                int k_test = 0; // square lights with a valid sample met so far
                 for (int l = 0; l < S.n_lights; l++)
                 {
                     const R *L;
@@ -254,7 +261,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                     V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
                     const R x1 = rng_draw<R>(key, sample, bnc, 4 * l + 0);
                     const R x2 = rng_draw<R>(key, sample, bnc, 4 * l + 1);
-                    const bool square = SQ && l == S.sq_light;
+                    const bool square = SQ && L[0] == R(0);
                     R pdf;
                     if (square)
                         pdf = square_light_sample(L, p, x1, x2, ro, rd);
@@ -267,12 +274,15 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                         continue;
                     if (square)
                     {
-                        if (vis == 0u)
+                        if (k_test == tested)
                         {
-                            defer = true;
+                            // the next test this bounce needs: out it goes
+                            defer = true, defer_light = l, defer_state = state;
                             break;
                         }
-                        if (vis == RING_BLOCKED)
+                        const bool blocked = ((state >> (RING_RESULT_SHIFT + k_test)) & 1u) != 0u;
+                        k_test++;
+                        if (blocked)
                             continue;
                     }
                     const V3<R> f = bxdf_eval(m, rd, wo, nrm);
@@ -314,10 +324,10 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 const V3<R> od = defer ? keep_d : wi;
                 Q.ro[r] = p.x, Q.ro[RING_CAP + r] = p.y, Q.ro[2 * RING_CAP + r] = p.z;
                 Q.rd[r] = od.x, Q.rd[RING_CAP + r] = od.y, Q.rd[2 * RING_CAP + r] = od.z;
-                Q.r_pid[r] = s_pid, Q.r_bounce[r] = defer ? (s_bounce | RING_SHADOW) : s_bounce + 1u;
+                Q.r_pid[r] = s_pid, Q.r_bounce[r] = defer ? defer_state : s_bounce + 1u;
                 Q.r_klo[r] = s_klo, Q.r_khi[r] = s_khi;
                 if (SQ)
-                    Q.r_tri[r] = keep_tri;
+                    Q.r_tri[r] = keep_tri, Q.r_light[r] = defer ? defer_light : -1;
             }
             rq_count += uint32_t(__popcll(cm));
         }
@@ -374,7 +384,9 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 Q.hd[r] = hd.x, Q.hd[RING_CAP + r] = hd.y, Q.hd[2 * RING_CAP + r] = hd.z;
                 Q.h_tri[r] = test ? vtri : T.target;
                 Q.h_pid[r] = pid, Q.h_klo[r] = klo, Q.h_khi[r] = khi;
-                Q.h_bounce[r] = test ? (bounce | (T.target == 1 ? RING_BLOCKED : RING_VISIBLE)) : bounce;
+                // a test adds its result bit and counts itself
+                const uint32_t k = (bounce >> RING_TESTS_SHIFT) & 15u;
+                Q.h_bounce[r] = test ? ((bounce | (T.target == 1 ? 1u << (RING_RESULT_SHIFT + k) : 0u)) + (1u << RING_TESTS_SHIFT)) : bounce;
                 busy = false, done = false;
             }
             hq_count += uint32_t(__popcll(gm));
@@ -413,6 +425,8 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 Q.ro[r] = cam_pos.x, Q.ro[RING_CAP + r] = cam_pos.y, Q.ro[2 * RING_CAP + r] = cam_pos.z;
                 Q.rd[r] = cd.x, Q.rd[RING_CAP + r] = cd.y, Q.rd[2 * RING_CAP + r] = cd.z;
                 Q.r_pid[r] = id, Q.r_bounce[r] = 0u, Q.r_klo[r] = uint32_t(key), Q.r_khi[r] = uint32_t(key >> 32);
+                if (SQ)
+                    Q.r_light[r] = -1;
             }
             next += cnt;
             rq_count += cnt;
@@ -429,22 +443,22 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 o = {Q.ro[r], Q.ro[RING_CAP + r], Q.ro[2 * RING_CAP + r]};
                 d = {Q.rd[r], Q.rd[RING_CAP + r], Q.rd[2 * RING_CAP + r]};
                 pid = Q.r_pid[r], bounce = Q.r_bounce[r], klo = Q.r_klo[r], khi = Q.r_khi[r];
-                if (SQ && (bounce & RING_SHADOW))
+                const int test_light = SQ ? Q.r_light[r] : -1;
+                if (SQ && test_light >= 0)
                 {
                     // a visibility test: the entry is the hit (point, incoming direction, triangle); the
                     // segment runs from the light sample point, a function of the path's random numbers,
                     // to the shaded point, as in visible()
-                    bounce &= RING_BOUNCE;
                     vp = o, vd = d, vtri = Q.r_tri[r];
                     const R *L;
                     if constexpr (TAB)
-                        L = lds_lights + S.sq_light * LIGHT_STRIDE;
+                        L = lds_lights + test_light * LIGHT_STRIDE;
                     else
-                        L = S.lights + (size_t)S.sq_light * LIGHT_STRIDE;
+                        L = S.lights + (size_t)test_light * LIGHT_STRIDE;
                     const uint64_t key = (uint64_t(khi) << 32) | klo;
                     const uint32_t sample = uint32_t(B.sample0) + pid / n_pix;
-                    const R x1 = rng_draw<R>(key, sample, bounce, 4 * S.sq_light + 0);
-                    const R x2 = rng_draw<R>(key, sample, bounce, 4 * S.sq_light + 1);
+                    const R x1 = rng_draw<R>(key, sample, bounce & RING_BOUNCE, 4 * test_light + 0);
+                    const R x2 = rng_draw<R>(key, sample, bounce & RING_BOUNCE, 4 * test_light + 1);
                     const V3<R> s = square_light_point(L, x1, x2);
                     const R dist = norm(s - vp);
                     o = s, d = normalized(vp - s);

@@ -645,11 +645,12 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
         pick(std::true_type());
     else
         pick(std::false_type());
-    if (!BRUTE && S.n_square <= 1 && rings)
+    if (!BRUTE && S.n_square <= 12 && rings)
     {
-        // at most one visibility test per bounce: the tracer that keeps more paths in flight than lanes
+        // the tracer that keeps more paths in flight than lanes (its state word counts up to 12
+        // visibility tests per bounce)
         p.rings = true;
-        const bool sq = S.n_square == 1;
+        const bool sq = S.n_square >= 1;
         if constexpr (sizeof(R) == 8)
             p.kernel = tab ? (sq ? k_trace_rings_f64<true, true> : k_trace_rings_f64<true, false>)
                            : (sq ? k_trace_rings_f64<false, true> : k_trace_rings_f64<false, false>);

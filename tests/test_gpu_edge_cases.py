@@ -215,3 +215,35 @@ def test_ring_tracer_with_one_square_light_among_sphere_lights(mis, position):
     assert not c_.accel_info()["brute_force"]
     assert st["shadow_rays"] > 0
     assert_f64_parity(img, oimg, st, ost)
+
+
+def test_ring_tracer_with_several_square_lights(mis):
+    """Every square light with a valid sample costs the hit one more trip round the rings; results
+    and test counts are those of the lane tracer and of the oracle."""
+    ref = copy.deepcopy(mis)
+    lo, hi = ref.verts.reshape(-1, 3).min(0), ref.verts.reshape(-1, 3).max(0)
+    rng = np.random.default_rng(11)
+    squares = []
+    for k in range(4):
+        c = lo + (hi - lo) * rng.uniform(0.2, 0.8, 3)
+        e = 0.08 * (hi - lo)
+        y = hi[1] - (0.05 + 0.1 * k) * (hi[1] - lo[1])
+        L = np.zeros(ref.lights.shape[1])
+        L[1:4] = rng.uniform(1.0, 6.0, 3)
+        L[4:16] = np.array([[c[0] - e[0], y, c[2] - e[2]], [c[0] + e[0], y, c[2] - e[2]],
+                            [c[0] + e[0], y, c[2] + e[2]], [c[0] - e[0], y, c[2] + e[2]]]).ravel()
+        squares.append(L)
+    lights = list(ref.lights)
+    for k, L in enumerate(squares):
+        lights.insert(2 * k, L)                                   # squares and spheres interleaved
+    ref.lights = np.array(lights)
+    img, st, oimg, ost, c_ = render_both(ref)
+    assert not c_.accel_info()["brute_force"]
+    assert st["shadow_rays"] > st["segments"]                      # more than one test per segment on average
+    assert_f64_parity(img, oimg, st, ost)
+    lane = pt.Context(0)
+    lane.set_option("bvh_rings", 0)
+    lane.build_accel(gpu_scene(ref))
+    limg, lst = lane.render(mode="f64", seed=13)
+    assert np.array_equal(limg, img)
+    assert (lst["segments"], lst["shadow_rays"], lst["records"]) == (st["segments"], st["shadow_rays"], st["records"])
