@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mode", default=os.environ.get("PTX_BENCH_MODE", "f64"), choices=["f64", "f32"])
     ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=0, help="image width (default: --size)")
+    ap.add_argument("--height", type=int, default=0, help="image height (default: --size)")
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--conf", default="config/cbox.conf")
     ap.add_argument("--batch-paths", type=int, default=0)
@@ -108,9 +110,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    W = H = args.size
+    W, H = args.width or args.size, args.height or args.size
     scene_name = os.path.splitext(os.path.basename(args.conf))[0]
-    headline = scene_name == "cbox" and args.size == 1024 and args.spp == 256
+    headline = scene_name == "cbox" and W == 1024 and H == 1024 and args.spp == 256
     scene = pt.Scene.load_conf(os.path.join(ROOT, args.conf), root_dir=ROOT, width=W, height=H, spp=args.spp)
     info = scene.info
     stream = torch.cuda.current_stream()
