@@ -60,12 +60,12 @@ def reference_stream_bytes(st, n_square):
     return st["paths"] * (seg_per_path * (b_seg + 24) + 12) + bvh
 
 
-def pmc_calibration(mode):
+def pmc_calibration(mode, scene="cbox"):
     """What only hardware counters can tell, from the committed PMC profile of this same command
     (tools/make_profiles.py): VALU instructions per 64-lane bounce iteration of the tracer
     (SQ_INSTS_VALU / wave iterations) and its HBM bytes per launch (FETCH_SIZE, WRITE_SIZE).  None
     when the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "calibration.json")
+    path = os.path.join(ROOT, "profiles", "calibration.json" if scene == "cbox" else "calibration_%s.json" % scene)
     try:
         with open(path) as f:
             return json.load(f).get(mode)
@@ -185,8 +185,8 @@ def main():
                             "in registers and LDS, so the bytes it must move (design_*) and the bytes it does move "
                             "(traffic, PMC) are far below that, and it is bound by vector-ALU issue, see valu"
                             % (stream_bytes * passes / max(ps["paths"], 1))}
-        # the committed counter calibration was collected on cbox; it says nothing about other scenes
-        cal = pmc_calibration(args.mode) if scene_name == "cbox" else None
+        # counter calibrations are per scene (and only quoted at the launch size they were collected at)
+        cal = pmc_calibration(args.mode, scene_name)
         if cal and dom == "trace" and cal.get("paths_per_launch") == paths_per_step // world // passes:
             roofline["traffic"] = cal.get("hbm_bytes_per_launch")
             roofline["traffic_source"] = cal.get("source")

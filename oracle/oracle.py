@@ -258,3 +258,49 @@ def rmse_rel(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.mean(np.sum((a - b) ** 2 / (b ** 2 + 1e-2), axis=-1)))
+
+
+class RefAccel:
+    """One of the reference's two culling structures over a triangle array (oracle/ref_accels.c):
+    RefAccel(verts, "AABB", subdivide) is cAABB, RefAccel(verts, "OCTREE", capacity) is cOctree
+    (src/geometry/cAccelStruct.cpp:89-263, 266-482, 614-730 of the reference)."""
+
+    def __init__(self, verts, kind, param):
+        L = lib()
+        L.orc_accel_build.restype = C.c_void_p
+        L.orc_accel_build.argtypes = [C.c_void_p, C.c_int32, C.c_int, C.c_int]
+        L.orc_accel_free.argtypes = [C.c_void_p]
+        L.orc_accel_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_accel_raycast_many.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_accel_vistest_many.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 9)
+        self.kind = kind
+        self._h = L.orc_accel_build(_p(self.verts), self.verts.shape[0], {"AABB": 1, "OCTREE": 2}[kind], int(param))
+        if not self._h:
+            raise RuntimeError("octree split recursion does not end (the reference overflows its stack here)")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_accel_free(self._h)
+            self._h = None
+
+    def info(self):
+        out = np.zeros(5, dtype=np.int64)
+        lib().orc_accel_info(self._h, _p(out))
+        return {"boxes": int(out[0]), "face_refs": int(out[1]), "stranded_refs": int(out[2]),
+                "unreachable_faces": int(out[3]), "reference_would_exit": int(out[4])}
+
+    def raycast(self, o, d):
+        o = np.ascontiguousarray(o, dtype=np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(d, dtype=np.float64).reshape(-1, 3)
+        ids = np.empty(o.shape[0], dtype=np.int32)
+        pts = np.empty((o.shape[0], 3), dtype=np.float64)
+        lib().orc_accel_raycast_many(self._h, o.shape[0], _p(o), _p(d), _p(ids), _p(pts))
+        return ids, pts
+
+    def vistest(self, p1, p2):
+        p1 = np.ascontiguousarray(p1, dtype=np.float64).reshape(-1, 3)
+        p2 = np.ascontiguousarray(p2, dtype=np.float64).reshape(-1, 3)
+        vis = np.empty(p1.shape[0], dtype=np.int32)
+        lib().orc_accel_vistest_many(self._h, p1.shape[0], _p(p1), _p(p2), _p(vis))
+        return vis.astype(bool)

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 databases of one profiling session into the summaries kept under profiles/.
 
-usage: make_profiles.py <tag> <bench.json> <kernel-trace.db> <sq-pmc.db> <fetch-pmc.db> <write-pmc.db>
+usage: make_profiles.py <tag> <bench.json> <kernel-trace.db> <sq-pmc.db> <fetch-pmc.db> <write-pmc.db> [scene]
 
 Writes profiles/<tag>_kernel_stats.csv (per-kernel calls / total / average, as rocprofv3 --stats
 reports them), profiles/<tag>_pmc.json (per-kernel counter sums and per-launch HBM traffic) and
-profiles/calibration.json (VALU instructions per 64-lane bounce iteration of the tracer and its
+profiles/calibration.json (calibration_<scene>.json for a scene other than cbox: VALU instructions per 64-lane bounce iteration of the tracer and its
 measured HBM bytes per launch, which bench.py quotes next to its live timings).
 """
 import collections
@@ -65,6 +65,7 @@ def short(name):
 
 def main():
     tag, bench_json, kt_db, sq_db, fetch_db, write_db = sys.argv[1:7]
+    scene = sys.argv[7] if len(sys.argv) > 7 else "cbox"
     out_dir = os.path.join(ROOT, "profiles")
     bench = json.loads(open(bench_json).read().strip().splitlines()[-1])
     with open(os.path.join(out_dir, tag + "_kernel_stats.csv"), "w") as f:
@@ -87,13 +88,13 @@ def main():
             e["hbm_read_bytes_per_launch"] = 2.0 * e["FETCH_SIZE"] * 1024 / e["launches"]
             e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE"] * 1024 / e["launches"]
     cal = {}
-    modes = {"f64": ("k_trace_f64", bench["step_stats"]["wave_iterations"] / bench["step_stats"]["passes"]),
-             "f32": ("k_trace_f32", bench["other_mode"]["wave_iterations"] / bench["other_mode"]["passes"])}
+    modes = {"f64": ("_f64", bench["step_stats"]["wave_iterations"] / bench["step_stats"]["passes"]),
+             "f32": ("_f32", bench["other_mode"]["wave_iterations"] / bench["other_mode"]["passes"])}
     if bench["dtype"] == "f32":
-        modes = {"f32": modes["f64"][:0] + ("k_trace_f32", modes["f64"][1]), "f64": ("k_trace_f64", modes["f32"][1])}
+        modes = {"f32": ("_f32", modes["f64"][1]), "f64": ("_f64", modes["f32"][1])}
     for mode, (kname, iters_per_launch) in modes.items():
         for k, e in pmc.items():
-            if kname in k and "SQ_INSTS_VALU" in e:
+            if "k_trace" in k and kname in k and "SQ_INSTS_VALU" in e:
                 cal[mode] = {"valu_insts_per_wave_iteration": round(e["SQ_INSTS_VALU"] / e["launches"] / iters_per_launch, 1),
                              "active_lanes_per_valu_inst": round(e["SQ_THREAD_CYCLES_VALU"] / e["SQ_ACTIVE_INST_VALU"] / 64.0, 4)
                              if e.get("SQ_ACTIVE_INST_VALU") else None,
@@ -101,7 +102,8 @@ def main():
                              "paths_per_launch": bench["config"]["paths_per_step"] // bench["step_stats"]["passes"],
                              "source": "profiles/%s_pmc.json (rocprofv3 --pmc on bench.py, %s)" % (tag, k)}
     json.dump(pmc, open(os.path.join(out_dir, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
-    json.dump(cal, open(os.path.join(out_dir, "calibration.json"), "w"), indent=1, sort_keys=True)
+    cal_name = "calibration.json" if scene == "cbox" else "calibration_%s.json" % scene
+    json.dump(cal, open(os.path.join(out_dir, cal_name), "w"), indent=1, sort_keys=True)
     print(json.dumps(cal, indent=1))
 
 
