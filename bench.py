@@ -180,10 +180,16 @@ def main():
                     "bytes_per_path": round(stream_bytes * passes / max(ps["paths"], 1), 1),
                     "design_bytes_per_launch": round(design_bytes), "design_achieved": round(design_gbs, 2),
                     "design_frac": round(design_gbs / HBM_PEAK_GBS, 5),
-                    "note": "achieved prices the data streams of the algorithm (f32 SoA ray / hit / shadow / stack "
-                            "streams, %.0f B per path on this scene); the tracer keeps rays, hits and light samples "
-                            "in registers and LDS, so the bytes it must move (design_*) and the bytes it does move "
-                            "(traffic, PMC) are far below that, and it is bound by vector-ALU issue, see valu"
+                    "note": ("achieved prices the data streams of the algorithm (f32 SoA ray / hit / shadow / stack "
+                             "streams, %.0f B per path on this scene); the tracer keeps rays, hits and light samples "
+                             "in registers and LDS, so the bytes it must move (design_*) and the bytes it does move "
+                             "(traffic, PMC) are far below that, and it is bound by vector-ALU issue, see valu"
+                             if ctx.accel_info()["brute_force"] else
+                             "achieved prices the data streams of the algorithm (f32 SoA ray / hit / shadow / stack "
+                             "streams plus 32 B per BVH node and 48 B per triangle visited, %.0f B per path on this "
+                             "scene); rays and hits stay in registers, LDS and wave-private rings, the BVH records and "
+                             "the path records do go through memory (traffic, PMC); the kernel is bound by memory "
+                             "latency and traversal divergence, see valu")
                             % (stream_bytes * passes / max(ps["paths"], 1))}
         # counter calibrations are per scene (and only quoted at the launch size they were collected at)
         cal = pmc_calibration(args.mode, scene_name)

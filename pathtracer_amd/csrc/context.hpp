@@ -86,7 +86,7 @@ public:
     // BVH tracer: at most this many traversal stack levels in LDS, deeper ones spill to global memory
     // (0: as many as fit at full occupancy)
     int lds_stack_levels = 0;
-    // BVH scenes with at most one square light: the tracer that queues hits and rays per wave (ring tracer)
+    // BVH scenes with at most 12 square lights: the tracer that queues hits and rays per wave (ring tracer)
     // instead of the one that keeps every path on its lane
     bool bvh_rings = true;
 
