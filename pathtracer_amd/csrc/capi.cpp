@@ -4,7 +4,9 @@
 #include "plane_records.hpp"
 #include "scene.hpp"
 
+#include <cmath>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <stdexcept>
 #include <algorithm>
@@ -79,17 +81,9 @@ int ptx_scene_load_conf(const char *conf_path, const char *root_dir, const ptx_o
             o.model = ov->model;
         o.full_region = ov->full_region != 0;
     }
-    auto *s = new ptx_scene();
-    try
-    {
-        ptx::load_conf(conf_path, root_dir ? root_dir : "", o, s->sc);
-    }
-    catch (...)
-    {
-        delete s;
-        throw;
-    }
-    *out = s;
+    std::unique_ptr<ptx_scene> s(new ptx_scene());
+    ptx::load_conf(conf_path, root_dir ? root_dir : "", o, s->sc);
+    *out = s.release();
     PTX_CATCH
 }
 
@@ -101,13 +95,18 @@ int ptx_scene_from_arrays(const float *verts, const float *normals, const int32_
 {
     if (!out || n_tris < 0 || n_mats < 0 || n_lights < 0 || (n_tris > 0 && (!verts || !mat_ids)) || !view16 || !cam_pos3)
         return fail_arg("ptx_scene_from_arrays: null or negative argument");
+    if ((n_mats > 0 && !mats) || (n_lights > 0 && !lights))
+        return fail_arg("ptx_scene_from_arrays: null material or light table");
     if (width <= 0 || height <= 0 || depth <= 0 || spp <= 0)
         return fail_arg("ptx_scene_from_arrays: width, height, depth and spp must be positive");
     *out = nullptr;
     PTX_TRY
-    auto *s = new ptx_scene();
+    std::unique_ptr<ptx_scene> s(new ptx_scene());
     ptx::Scene &sc = s->sc;
     sc.verts.assign(verts, verts + static_cast<size_t>(n_tris) * 9);
+    for (float x : sc.verts)
+        if (!std::isfinite(x))
+            throw std::runtime_error("arg: vertex coordinate is not finite");
     sc.has_normals = normals != nullptr;
     if (normals)
         sc.normals.assign(normals, normals + static_cast<size_t>(n_tris) * 9);
@@ -116,11 +115,8 @@ int ptx_scene_from_arrays(const float *verts, const float *normals, const int32_
     sc.mat_ids.assign(mat_ids, mat_ids + n_tris);
     sc.vert_ids.assign(static_cast<size_t>(n_tris) * 3, -1);
     for (int i = 0; i < n_tris; i++)
-        if (sc.mat_ids[i] >= n_mats)
-        {
-            delete s;
-            throw std::runtime_error("arg: material id out of range");
-        }
+        if (sc.mat_ids[i] >= n_mats || sc.mat_ids[i] < -1)
+            throw std::runtime_error("arg: material id out of range (-1 = no material)");
     for (int i = 0; i < n_mats; i++)
     {
         ptx::Material m;
@@ -159,7 +155,7 @@ int ptx_scene_from_arrays(const float *verts, const float *normals, const int32_
     sc.enable_indirect = enable_indirect != 0, sc.enable_bary_normal = enable_bary_normal != 0;
     sc.region[0] = 0, sc.region[1] = 0, sc.region[2] = height, sc.region[3] = width;
     sc.update_camera();
-    *out = s;
+    *out = s.release();
     PTX_CATCH
 }
 

@@ -322,6 +322,8 @@ void load_obj(const std::string &path, double scale, const double disp[3], Scene
             {
                 // tinyobj::real_t vx = (attrib.vertices[..] + disp[c]) * scale  -> rounded to float
                 double w = (static_cast<double>(v[a * 3 + c]) + disp[c]) * scale;
+                if (!std::isfinite(static_cast<float>(w)))
+                    throw std::runtime_error("parse: OBJ vertex coordinate is not finite in " + path);
                 out.verts[i * 9 + j * 3 + c] = static_cast<float>(w);
             }
             int b = fn[i][j];

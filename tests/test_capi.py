@@ -67,3 +67,30 @@ def test_scene_from_arrays_roundtrip():
     assert np.array_equal(s.geometry()[0], verts)
     with pytest.raises(pt.PtxError):
         pt.Scene.from_arrays(verts, None, [3], mats, lights, view, (0, 0, 5), 45.0, 0.1, 16, 8, 3, 2)
+    with pytest.raises(pt.PtxError):        # below -1 (= no material)
+        pt.Scene.from_arrays(verts, None, [-2], mats, lights, view, (0, 0, 5), 45.0, 0.1, 16, 8, 3, 2)
+    bad = verts.copy()
+    bad[0, 1, 2] = np.inf
+    with pytest.raises(pt.PtxError):
+        pt.Scene.from_arrays(bad, None, [0], mats, lights, view, (0, 0, 5), 45.0, 0.1, 16, 8, 3, 2)
+    bad[0, 1, 2] = np.nan
+    with pytest.raises(pt.PtxError):
+        pt.Scene.from_arrays(bad, None, [0], mats, lights, view, (0, 0, 5), 45.0, 0.1, 16, 8, 3, 2)
+    s2 = pt.Scene.from_arrays(verts, None, [-1], mats, lights, view, (0, 0, 5), 45.0, 0.1, 16, 8, 3, 2)
+    assert s2.geometry()[2].tolist() == [-1]
+
+
+def test_obj_with_a_non_finite_vertex_is_a_parse_error(tmp_path):
+    import json
+    (tmp_path / "m.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 inf 0\nf 1 2 3\n")
+    conf = {"MainWindowInfo": {"Width": 8, "Height": 8},
+            "Scene": {"ModelName": "m.obj", "WorldScale": 1.0, "ModelDisplacement": [0, 0, 0, 0]},
+            "Camera": {"Type": "FPS", "CameraPos": [0, 0, 5], "CameraFront": [0, 0, -1], "CameraUp": [0, 1, 0],
+                       "CameraFov": 45, "CameraNear": 0.1},
+            "PathTracer": {"Depth": 2, "Samples": 1, "ResultPath": "o.ppm", "EnableIndirectLight": True,
+                           "EnableBarycentricNormal": True, "DrawRegion": [0, 0, 8, 8], "RayCastAccel": {"Type": "None"}},
+            "Light": {"LightNum": 0, "LightType": [], "LightInfo": [], "LightRadiance": []}}
+    (tmp_path / "c.conf").write_text(json.dumps(conf))
+    with pytest.raises(pt.PtxError) as e:
+        pt.Scene.load_conf(str(tmp_path / "c.conf"), root_dir=str(tmp_path))
+    assert "finite" in str(e.value)
