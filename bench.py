@@ -279,10 +279,13 @@ def cpu_baseline_and_checks(ctx, args, W, H):
     o2 = oracle.Oracle(ref, seed=14).render(spp=spp, threads=threads) if spp <= 4 else None
     rmse = oracle.rmse_rel(gimg, oimg)
     floor = oracle.rmse_rel(o2, oimg) if o2 is not None else None
+    # tolerance: max(2 x the oracle's own two-seed noise floor, 1e-3); the floor costs a second CPU
+    # render and is only measured at low spp -- without it the bar is the 1e-3 it can never go below
+    tol = 1e-3 if floor is None else max(2 * floor, 1e-3)
     checks = {"first_hit_mismatches": int((ids != oids).sum()), "first_hit_pixels": int(ids.size),
-              "rmse_vs_cpu_equal_spp": rmse, "spp": spp,
-              "rmse_tolerance": None if floor is None else max(2 * floor, 1e-3),
-              "oracle_two_seed_rmse": floor}
+              "rmse_vs_cpu_equal_spp": rmse, "spp": spp, "rmse_tolerance": tol,
+              "oracle_two_seed_rmse": floor,
+              "pass": bool((ids == oids).all() and rmse <= tol)}
     return cpu, checks
 
 
