@@ -104,3 +104,20 @@ def test_report_runs(root):
     r = ref_accel_report.report("config/cbox.conf", 16, 100, structures=(("OCTREE", 30),))
     s = r["structures"]["OCTREE 30"]
     assert r["faces"] == 26 and s["camera"]["rays"] == 256 and s["camera"]["different_face"] == 0
+
+
+def test_room_stand_in_loads_into_the_reference_octree(root, room_scene):
+    # config/room.conf names OCTREE with capacity 90; the stand-in must be a mesh that builder can
+    # take (no `capacity` faces round one point, no face in a split plane) and is answered alike
+    ref = scene_io.load_conf(os.path.join(root, "config/room.conf"), root_dir=root, width=32, height=32, spp=1)
+    ref.use_bvh = True
+    v = ref.verts.reshape(-1, 3, 3)
+    assert (np.linalg.norm(np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 1]), axis=1) > 0).all()
+    A = oracle.RefAccel(ref.verts, "OCTREE", 90)
+    info = A.info()
+    assert info["reference_would_exit"] == 0 and info["unreachable_faces"] == 0 and info["stranded_refs"] == 0
+    O = oracle.Oracle(ref, seed=13)
+    o, d = O.generate_rays()
+    ids, pts = O.first_hit(with_points=True)
+    got_ids, got_pts = A.raycast(o, d)
+    assert np.array_equal(got_ids, ids) and np.array_equal(got_pts[ids >= 0], pts[ids >= 0])
