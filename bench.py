@@ -106,7 +106,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the path-tracing core has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # launched by torch.distributed.run (RANK and MASTER_PORT set): the collectives run whatever the
+    # world size, so that a one-rank launch on a one-GPU box goes through the same RCCL calls as N > 1
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -129,11 +132,12 @@ def main():
     def step(profile=False, mode=None, reduce=True):
         # samples: rank r renders samples [r*spp, (r+1)*spp) of every pixel; bands: its rows of the
         # frame (the rest of `out` stays zero); then RCCL reduce(sum) -> rank 0
-        return render_frame(render_fn, out, spp_total, rank, world, scheme=args.scheme, reduce=reduce,
+        return render_frame(render_fn, out, spp_total, rank, world, scheme=args.scheme, reduce=reduce and use_dist,
+                            collective=use_dist,
                             mode=mode or args.mode, seed=13, profile=profile)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -145,7 +149,7 @@ def main():
         st = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -244,7 +248,7 @@ def main():
                            "wave_iterations": int(ost["wave_iterations"]), "passes": int(ost["passes"])},
             "cpu_baseline": cpu, "checks": checks,
         }
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -23,10 +23,12 @@ def shard_bands(rank, world, band=8):
     return dict(row_stride=int(world), row_phase=int(rank), band=int(band))
 
 
-def render_frame(render_fn, out, spp_total, rank=0, world=1, scheme="samples", band=8, reduce=True, **kw):
+def render_frame(render_fn, out, spp_total, rank=0, world=1, scheme="samples", band=8, reduce=True,
+                 collective=None, **kw):
     """Renders this rank's share into `out` (a torch tensor [H,W,3] float64 on the rank's device)
     and reduces onto rank 0.  `render_fn(out, **options)` fills `out` with pre-clamp sums; for the
-    GPU core it is `lambda out, **o: ctx.render_device(out.data_ptr(), **o)`."""
+    GPU core it is `lambda out, **o: ctx.render_device(out.data_ptr(), **o)`.  `collective`: run
+    the reduce even in a world of one (default: only when world > 1)."""
     if scheme == "samples":
         offset, count = shard_samples(spp_total, rank, world)
         if count > 0:
@@ -38,7 +40,7 @@ def render_frame(render_fn, out, spp_total, rank=0, world=1, scheme="samples", b
         stats = render_fn(out, spp=spp_total, sample_offset=0, spp_total=spp_total, **shard_bands(rank, world, band), **kw)
     else:
         raise ValueError("scheme must be 'samples' or 'bands'")
-    if reduce and world > 1:
+    if reduce and (world > 1 if collective is None else collective):
         import torch.distributed as dist
         dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
     return stats
