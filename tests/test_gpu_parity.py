@@ -326,6 +326,30 @@ def test_full_size_properties(root):
     assert_f64_parity(a[500:516, 480:544], oimg[500:516, 480:544])
 
 
+def test_full_size_properties_bvh_scene(root, room_scene):
+    """room (336 k triangles, BVH, ring tracer) at 1024 x 1024: cuts of the frame add up to the
+    frame, and a window of it equals the oracle rendering only that window."""
+    s, ref = load(root, "config/room.conf", width=1024, height=1024, spp=2)
+    ref.use_bvh = True
+    c = make_ctx(s)
+    assert not c.accel_info()["brute_force"]
+    a, sa = c.render(mode="f64", spp=2)
+    b, sb = c.render(mode="f64", spp=2, batch_paths=1 << 19)
+    assert np.array_equal(a, b) and sa["segments"] == sb["segments"] and sb["passes"] > sa["passes"]
+    bands = [c.render(mode="f64", spp=2, row_stride=2, row_phase=k, band=8)[0] for k in range(2)]
+    assert np.array_equal(bands[0] + bands[1], a)                       # disjoint rows: exact union
+    assert (bands[0][8:16] == 0).all() and (bands[1][0:8] == 0).all()
+    halves = [c.render(mode="f64", spp=1, sample_offset=k, spp_total=2)[0] for k in range(2)]
+    assert np.abs(halves[0] + halves[1] - a).max() <= 1e-15 * max(1.0, a.max())
+    ids = c.first_hit()
+    assert (a[(ids == -1).reshape(1024, 1024)] == 0).all()
+    ref.region = (600, 400, 607, 527)
+    O = oracle.Oracle(ref, seed=13)
+    oimg = O.render()
+    assert_f64_parity(a[600:608, 400:528], oimg[600:608, 400:528], depth=5)
+    assert np.array_equal(ids.reshape(1024, 1024)[600:608, 400:528], O.first_hit().reshape(1024, 1024)[600:608, 400:528])
+
+
 def test_pathtracer_process_writes_reference_format_ppm(root, tmp_path):
     import json
     conf = json.load(open(os.path.join(root, "config/cbox.conf")))
