@@ -10,13 +10,17 @@ per-pixel sums are reduced onto rank 0 over RCCL inside the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode f64|f32] [--spp S] [--size W]
 
-For N > 1 launch through `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
-Rank 0 prints ONE JSON line.  Inputs are resident in HBM when the timed region starts; the output
-is a device buffer (no PCIe traffic inside the timed region).
+N > 1: either under a launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N`, one rank per GPU) or plainly as `python bench.py --gpus N`, in which case this process
+starts that launcher itself -- before it has touched a GPU -- relays rank 0's line and exits with
+the ranks' status.  Rank 0 prints ONE JSON line.  Inputs are resident in HBM when the timed region
+starts; the output is a device buffer (no PCIe traffic inside the timed region).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -73,6 +77,51 @@ def pmc_calibration(mode, scene="cbox"):
         return None
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks of this same
+    command under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1), pass
+    everything they print on stderr through, print rank 0's JSON line, return their exit status.
+    Nothing in this process has initialised a GPU."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between processes here
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+def host_cpu():
+    """(model string of the host CPU, logical CPUs of the machine, CPUs this process may run on)"""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 1
+    return model, os.cpu_count() or 1, usable
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,43 +140,60 @@ def main():
                     help="multi-GPU sharding: 'samples' = every rank renders --spp samples of every pixel (weak "
                          "scaling, the default), 'bands' = the ranks share the rows of one --spp frame in interleaved "
                          "bands of 8 (strong scaling)")
+    ap.add_argument("--rehearse", default="",
+                    help="(tests) MODULE whose setup(args, rank, world, W, H) returns (render_fn, out tensor): the launch, "
+                         "the sharding, the reduce, the timing and the result line run over gloo on the CPU with that "
+                         "render function in place of the GPU core; the line is marked as a rehearsal and is no measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
-
-    import pathtracer_amd as pt
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the path-tracing core has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+        raise SystemExit("bench.py --gpus %d inside a launcher of %d ranks: the two must agree" % (args.gpus, world))
+    rehearsal = bool(args.rehearse)
+    if not rehearsal:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the path-tracing core has no CPU fallback")
+        torch.cuda.set_device(local_rank)
     # launched by torch.distributed.run (RANK and MASTER_PORT set): the collectives run whatever the
     # world size, so that a one-rank launch on a one-GPU box goes through the same RCCL calls as N > 1
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     W, H = args.width or args.size, args.height or args.size
     scene_name = os.path.splitext(os.path.basename(args.conf))[0]
     headline = scene_name == "cbox" and W == 1024 and H == 1024 and args.spp == 256
-    scene = pt.Scene.load_conf(os.path.join(ROOT, args.conf), root_dir=ROOT, width=W, height=H, spp=args.spp)
-    info = scene.info
-    stream = torch.cuda.current_stream()
-    ctx = pt.Context(local_rank, stream=stream.cuda_stream, batch_paths=args.batch_paths or None)
-    ctx.build_accel(scene)
-    out = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
     spp_total = args.spp * world if args.scheme == "samples" else args.spp
 
     from pathtracer_amd.distributed import render_frame
 
-    def render_fn(o, **kw):
-        return ctx.render_device(o.data_ptr(), **kw)
+    if rehearsal:
+        import importlib
+        render_fn, out = importlib.import_module(args.rehearse).setup(args, rank, world, W, H)
+        ctx = info = None
+    else:
+        import pathtracer_amd as pt
+        scene = pt.Scene.load_conf(os.path.join(ROOT, args.conf), root_dir=ROOT, width=W, height=H, spp=args.spp)
+        info = scene.info
+        stream = torch.cuda.current_stream()
+        ctx = pt.Context(local_rank, stream=stream.cuda_stream, batch_paths=args.batch_paths or None)
+        ctx.build_accel(scene)
+        out = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+
+        def render_fn(o, **kw):
+            return ctx.render_device(o.data_ptr(), **kw)
 
     def step(profile=False, mode=None, reduce=True):
         # samples: rank r renders samples [r*spp, (r+1)*spp) of every pixel; bands: its rows of the
@@ -139,7 +205,8 @@ def main():
     def fence():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not rehearsal:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -150,14 +217,23 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=out.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     paths_per_step = W * H * spp_total
     value = paths_per_step * args.steps / dt / 1e6
 
     result = None
-    if rank == 0:
+    if rank == 0 and rehearsal:
+        result = {"metric": "Mpaths/s at %s %dx%d (whole job, all ranks)" % (scene_name, W, H), "value": round(value, 6),
+                  "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                  "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+                  "scaling": "weak" if args.scheme == "samples" else "strong", "vs_baseline": None, "dtype": args.mode,
+                  "data": "rehearsal on the CPU over gloo (%s): no measurement" % args.rehearse,
+                  "config": {"workload": "%s %dx%d, %d spp per rank" % (scene_name, W, H, args.spp), "global_spp": spp_total,
+                             "paths_per_step": paths_per_step},
+                  "frame_checksum": float(out.double().sum().item()), "roofline": None, "cpu_baseline": None}
+    elif rank == 0:
         # ---- roofline of the dominant kernel: one more step with HIP events around every launch
         # on the render stream (same workload, same stream; not part of the timed region above)
         ps = step(profile=True, reduce=False)   # rank 0 only: no collective in here
@@ -260,7 +336,10 @@ def cpu_baseline_and_checks(ctx, args, W, H):
     same workload, and the two correctness gates next to the throughput number."""
     from oracle import oracle, scene_io
 
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    # every CPU this process may run on (its affinity mask / the harness's OMP_NUM_THREADS share of a
+    # larger host), not a fixed cap
+    model, host_cpus, usable = host_cpu()
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or usable
     ref = scene_io.load_conf(os.path.join(ROOT, args.conf), root_dir=ROOT, width=W, height=H, spp=1)
     O = oracle.Oracle(ref, seed=13)
     # calibrate on a few rows, then pick the spp that fills the time budget
@@ -273,6 +352,8 @@ def cpu_baseline_and_checks(ctx, args, W, H):
     oimg, ost = O.render(spp=spp, threads=threads, stats=True)
     cpu_dt = time.perf_counter() - t0
     cpu = {"value": round(W * H * spp / cpu_dt / 1e6, 4), "unit": "Mpaths/s", "cores": threads, "kind": "port",
+           "cpu_model": model, "host_logical_cpus": host_cpus, "cpus_usable_by_this_process": usable,
+           "threads_from": "OMP_NUM_THREADS" if os.environ.get("OMP_NUM_THREADS") else "affinity mask",
            "sample": "%s %dx%d at %d spp (%.1f s, oracle/pt_oracle.c, OpenMP dynamic over rows, f64, %s)"
                      % (os.path.splitext(os.path.basename(args.conf))[0], W, H, spp, cpu_dt,
                         "BVH" if ref.verts.shape[0] > 256 else "all-triangles loop")}

@@ -173,6 +173,28 @@ int ptx_raycast(ptx_context *, const double *rays_o, const double *rays_d, int64
                 int32_t *face_ids, double *hit_pts);
 int ptx_vistest(ptx_context *, const double *p1, const double *p2, int64_t n, int32_t *visible);
 
+/* ---- one frame over several GPUs of one node ---------------------------------------------------
+ * ptx_render_sharded shards the row loop of cPathTracer::RayTracing (src/tracing/cPathTracer.cpp:
+ * 526-529: OpenMP over rows inside one process) across n contexts, one per GPU, each driven by a
+ * host thread of its own; every context must hold the same scene (ptx_build_accel).
+ *   scheme   PTX_SHARD_SAMPLES: context i renders a contiguous range of the opts->spp samples of
+ *            every pixel; PTX_SHARD_BANDS: its interleaved bands of opts->band rows (0 = 8) of
+ *            the whole frame, band b going to context b mod n.
+ *   exchange the one data exchange, after the render: the per-pixel sums of all contexts are
+ *            reduced onto the GPU of context 0 by PTX_EXCHANGE_RCCL (ncclReduce, f64 sum, over
+ *            xGMI; librccl.so is looked up at the first call; every context on a GPU of its own)
+ *            or by PTX_EXCHANGE_PEER (peer copies added in context order: a fixed sum order;
+ *            contexts may share a GPU).
+ * rgb_sum: HOST buffer [H*W][3], the same pre-clamp sums as ptx_render writes (bands: bit for bit
+ * those of a single ptx_render; sample ranges: up to the order of the additions).  stats: n
+ * entries, one per context, or NULL.  opts->row_stride/row_phase/accumulate are ignored. */
+#define PTX_SHARD_SAMPLES 0
+#define PTX_SHARD_BANDS 1
+#define PTX_EXCHANGE_RCCL 0
+#define PTX_EXCHANGE_PEER 1
+int ptx_render_sharded(ptx_context *const *contexts, int32_t n, const ptx_render_opts *opts, int32_t scheme,
+                       int32_t exchange, double *rgb_sum, ptx_stats *stats);
+
 /* ---- image output --------------------------------------------------------------------------
  * ptx_finalize_image: the last per-pixel max-clamp (src/tracing/cPathTracer.cpp:701-702), host.
  * ptx_write_ppm: cPathTracer::OutputImage (src/tracing/cPathTracer.cpp:261-284): "P3\nW H\n255\n"

@@ -51,6 +51,9 @@ def lib():
         L.orc_tri_raycast.restype = C.c_int
         L.orc_tri_raycast_t.restype = C.c_double
         L.orc_closest_hit.restype = C.c_int32
+        L.orc_closest_hit_probe.restype = C.c_int32
+        L.orc_trace_sample.restype = C.c_int32
+        L.orc_trace_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_vistest.restype = C.c_int
         L.orc_square_light_sample.restype = C.c_double
         L.orc_square_light_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double,
@@ -141,6 +144,23 @@ class Oracle:
     def vistest(self, p1, p2):
         p1, p2 = _v3(p1), _v3(p2)
         return bool(lib().orc_vistest(C.byref(self.c), _p(p1), _p(p2)))
+
+    def closest_hit_probe(self, o, d):
+        """closest_hit plus the runner-up's distance (inf: none): (face, point, second)."""
+        o, d = _v3(o), _v3(d)
+        pt = np.zeros(3)
+        second = C.c_double(0.0)
+        f = lib().orc_closest_hit_probe(C.byref(self.c), _p(o), _p(d), _p(pt), C.byref(second))
+        return int(f), pt, float(second.value)
+
+    def trace_sample(self, x, y, sample):
+        """One sample of pixel (column x, row y): (rgb before the division by the sample count,
+        faces hit per bounce, margin by which each won its closest-hit search)."""
+        rgb = np.zeros(3)
+        faces = np.full(64, -2, dtype=np.int32)
+        margins = np.full(64, np.inf)
+        n = lib().orc_trace_sample(C.byref(self.c), int(x), int(y), int(sample), _p(rgb), _p(faces), _p(margins))
+        return rgb, faces[:n].copy(), margins[:n].copy()
 
     # -- render --------------------------------------------------------------------------------
     def render(self, spp=None, sample_offset=0, spp_total=None, threads=0, stats=False):

@@ -91,7 +91,10 @@ static inline uint64_t mix64(uint64_t z)
 uint64_t orc_rng_bits(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t dim)
 {
     uint64_t h = mix64(seed + 0x9E3779B97F4A7C15ULL * ((uint64_t)pixel + 1));
-    h = mix64(h ^ (((uint64_t)sample << 32) | ((uint64_t)bounce << 8) | (uint64_t)dim));
+    /* dimension split round the bounce field (bits 8-23) so that dimensions from 256 on (scenes
+     * with 64 or more lights) do not run into it */
+    h = mix64(h ^ (((uint64_t)sample << 32) | ((uint64_t)(dim >> 8) << 24) | ((uint64_t)bounce << 8) |
+                   (uint64_t)(dim & 255u)));
     return h;
 }
 
@@ -324,11 +327,25 @@ static inline int ray_box(const orc_bvh_node *nd, const double *o, const double 
 /* cAccelStruct::RayCast (cAccelStruct.cpp:28-54): closest hit, faces in ascending id, strict    */
 /* '<' so ties keep the lowest id; hits with dist <= 1e-6 ignored.  Returns face id or -1.       */
 /* ------------------------------------------------------------------------------------------ */
+/* Tie probe (test diagnostics, no counterpart in the reference): when `second` is given it
+ * receives the smallest accepted distance (> 1e-6) of a face OTHER than the winner -- infinity
+ * when there is none.  second - |pt - o| is the margin by which the winner won; a margin of a few
+ * ulps means the choice hinges on the last bit of the ray (coplanar overlapping faces, shared
+ * edges).  The BVH variant culls boxes beyond (1 + 1e-9) of the best distance, so it reports
+ * runners-up inside that band exactly and may report a larger value (or infinity) otherwise. */
+static inline void runner_up(double n, const double *dist, double *second)
+{
+    if (n < *dist)
+        *second = *dist; /* the old winner becomes the runner-up */
+    else if (n < *second)
+        *second = n;
+}
+
 static int32_t closest_brute(const orc_scene *sc, const double *o, const double *d, double *pt,
-                             orc_stats *st)
+                             orc_stats *st, double *second)
 {
     int32_t target = -1;
-    double dist = 1.7976931348623157e308;
+    double dist = 1.7976931348623157e308, snd = INFINITY;
     pt[0] = pt[1] = pt[2] = NAN;
     for (int32_t f = 0; f < sc->n_tris; f++)
     {
@@ -342,6 +359,8 @@ static int32_t closest_brute(const orc_scene *sc, const double *o, const double 
             continue;
         double e[3] = {p[0] - o[0], p[1] - o[1], p[2] - o[2]};
         double n = norm3(e);
+        if (n > 1e-6)
+            runner_up(n, &dist, &snd);
         if (n < dist && n > 1e-6)
         {
             pt[0] = p[0], pt[1] = p[1], pt[2] = p[2];
@@ -349,22 +368,27 @@ static int32_t closest_brute(const orc_scene *sc, const double *o, const double 
             target = f;
         }
     }
+    if (second)
+        *second = target < 0 ? INFINITY : (snd > 1e308 ? INFINITY : snd);
     return target;
 }
 
 static int32_t closest_bvh(const orc_scene *sc, const double *o, const double *d, double *pt,
-                           orc_stats *st)
+                           orc_stats *st, double *second)
 {
     int32_t target = -1;
-    double dist = 1.7976931348623157e308;
+    double dist = 1.7976931348623157e308, snd = INFINITY;
     pt[0] = pt[1] = pt[2] = NAN;
     int32_t stack[128];
     int sp = 0;
     stack[sp++] = 0;
+    /* the winner is chosen by distance |p - o|, the boxes are culled by ray parameter: 1 / |d|
+     * converts (the direction may have any length, tRay::Init does not normalise) */
+    const double per_len = 1.0 / norm3(d);
     while (sp)
     {
         const orc_bvh_node *nd = &g_bvh_nodes[stack[--sp]];
-        if (!ray_box(nd, o, d, dist * (1 + 1e-9) + 1e-9))
+        if (!ray_box(nd, o, d, dist * per_len * (1 + 1e-9) + 1e-9))
             continue;
         if (nd->left < 0)
         {
@@ -380,6 +404,8 @@ static int32_t closest_bvh(const orc_scene *sc, const double *o, const double *d
                     continue;
                 double e[3] = {p[0] - o[0], p[1] - o[1], p[2] - o[2]};
                 double n = norm3(e);
+                if (n > 1e-6)
+                    runner_up(n, &dist, &snd);
                 /* same winner as the ascending-id strict-'<' loop: smaller dist, ties -> lower id */
                 if (n > 1e-6 && (n < dist || (n == dist && f < target)))
                 {
@@ -395,24 +421,34 @@ static int32_t closest_bvh(const orc_scene *sc, const double *o, const double *d
             stack[sp++] = nd->right;
         }
     }
+    if (second)
+        *second = target < 0 ? INFINITY : (snd > 1e308 ? INFINITY : snd);
     return target;
 }
 
 int32_t orc_closest_hit(const orc_scene *sc, const double *o, const double *d, double *pt)
 {
     if (sc->use_bvh && g_bvh_nodes)
-        return closest_bvh(sc, o, d, pt, NULL);
-    return closest_brute(sc, o, d, pt, NULL);
+        return closest_bvh(sc, o, d, pt, NULL, NULL);
+    return closest_brute(sc, o, d, pt, NULL, NULL);
+}
+
+/* closest hit plus the runner-up distance (see runner_up above) */
+int32_t orc_closest_hit_probe(const orc_scene *sc, const double *o, const double *d, double *pt, double *second)
+{
+    if (sc->use_bvh && g_bvh_nodes)
+        return closest_bvh(sc, o, d, pt, NULL, second);
+    return closest_brute(sc, o, d, pt, NULL, second);
 }
 
 static int32_t closest(const orc_scene *sc, const double *o, const double *d, double *pt,
-                       orc_stats *st)
+                       orc_stats *st, double *second)
 {
     if (st)
         st->closest_rays++;
     if (sc->use_bvh && g_bvh_nodes)
-        return closest_bvh(sc, o, d, pt, st);
-    return closest_brute(sc, o, d, pt, st);
+        return closest_bvh(sc, o, d, pt, st, second);
+    return closest_brute(sc, o, d, pt, st, second);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -896,7 +932,7 @@ void orc_first_hit(const orc_scene *sc, int32_t *ids, double *pts)
             size_t id = (size_t)y * sc->width + x;
             double o[3], d[3], p[3];
             primary_ray(sc, mat, x, y, o, d);
-            ids[id] = closest(sc, o, d, p, NULL);
+            ids[id] = closest(sc, o, d, p, NULL, NULL);
             if (pts)
                 pts[id * 3] = p[0], pts[id * 3 + 1] = p[1], pts[id * 3 + 2] = p[2];
         }
@@ -907,6 +943,104 @@ void orc_first_hit(const orc_scene *sc, int32_t *ids, double *pts)
 /* sum_out receives the pre-final-clamp sum  (sum_s final_s / spp_total)                         */
 /* ------------------------------------------------------------------------------------------ */
 #define ORC_MAX_DEPTH 64
+/* per-bounce diagnostics of one sample (tests only): the face hit (-1: miss) and the margin by
+ * which it won its closest-hit search (runner-up distance minus its own; infinity: no runner-up) */
+typedef struct
+{
+    int32_t n;
+    int32_t face[ORC_MAX_DEPTH];
+    double margin[ORC_MAX_DEPTH];
+} orc_probe;
+
+/* one iteration of the sample loop (cPathTracer.cpp:578-693): final = the sample's radiance after
+ * the back-to-front combine, before the division by the sample count */
+static void trace_sample(const orc_scene *sc, const double *o0, const double *d0, uint32_t pixel,
+                         uint32_t sample, double *final, orc_stats *st, orc_probe *probe)
+{
+    int depth = sc->depth > ORC_MAX_DEPTH ? ORC_MAX_DEPTH : sc->depth;
+    double o[3] = {o0[0], o0[1], o0[2]}, d[3] = {d0[0], d0[1], d0[2]};
+    double D[ORC_MAX_DEPTH][3], C[ORC_MAX_DEPTH][3];
+    int len = 0;
+    final[0] = final[1] = final[2] = 0;
+    if (st)
+        st->paths++;
+    if (probe)
+        probe->n = 0;
+    for (int bounce = 0; bounce < depth; bounce++)
+    {
+        double p[3], second = INFINITY;
+        if (st)
+            st->segments++;
+        int32_t f = closest(sc, o, d, p, st, probe ? &second : NULL);
+        if (probe)
+        {
+            double e[3] = {p[0] - o[0], p[1] - o[1], p[2] - o[2]};
+            probe->face[probe->n] = f;
+            probe->margin[probe->n] = f < 0 ? INFINITY : second - norm3(e);
+            probe->n++;
+        }
+        int32_t mid;
+        if (f < 0 || (mid = sc->mat_ids[f]) == -1)
+        {
+            final[0] = final[1] = final[2] = 0;
+            break;
+        }
+        const double *mat_ = sc->mats + (size_t)mid * 12;
+        if (norm3(mat_) > 1e-6)
+        {
+            final[0] = mat_[0], final[1] = mat_[1], final[2] = mat_[2];
+            break;
+        }
+        const double *v = sc->verts + (size_t)f * 9;
+        double n[3];
+        if (sc->enable_bary_normal)
+        {
+            double w[3], acc[3] = {0, 0, 0};
+            const double *vn = sc->normals + (size_t)f * 9;
+            orc_barycentric(p, v, v + 3, v + 6, w);
+            for (int i = 0; i < 3; i++)
+                for (int k = 0; k < 3; k++)
+                    acc[k] += w[i] * vn[i * 3 + k];
+            normalize3(acc, n);
+        }
+        else
+            orc_normal_from_3pts(v, v + 3, v + 6, n);
+
+        nee(sc, mat_, n, p, d, pixel, sample, (uint32_t)bounce, D[len], st);
+        if (sc->enable_indirect)
+        {
+            double wo[3] = {-d[0], -d[1], -d[2]}, wi[3], xi[2];
+            xi[0] = orc_rng(sc->seed, pixel, sample, (uint32_t)bounce, 4 * sc->n_lights + 0);
+            xi[1] = orc_rng(sc->seed, pixel, sample, (uint32_t)bounce, 4 * sc->n_lights + 1);
+            orc_bxdf_sample(mat_, n, wo, xi, wi, C[len]);
+            len++;
+            for (int i = 0; i < 3; i++)
+                o[i] = p[i], d[i] = wi[i];
+        }
+        else
+        {
+            C[len][0] = C[len][1] = C[len][2] = 0;
+            len++;
+            break;
+        }
+    }
+    for (int i = len - 1; i >= 0; i--)
+    {
+        for (int k = 0; k < 3; k++)
+            final[k] = D[i][k] + C[i][k] * final[k];
+        double m = final[0];
+        if (final[1] > m)
+            m = final[1];
+        if (final[2] > m)
+            m = final[2];
+        if (0.0 > m)
+            m = 0.0; /* the 4th component is 0 and takes part in maxCoeff */
+        if (m > 1)
+            for (int k = 0; k < 3; k++)
+                final[k] /= m;
+    }
+}
+
 static void trace_pixel(const orc_scene *sc, const double *mat, int x, int y, double *sum_out,
                         orc_stats *st)
 {
@@ -914,86 +1048,35 @@ static void trace_pixel(const orc_scene *sc, const double *mat, int x, int y, do
     double o0[3], d0[3];
     primary_ray(sc, mat, x, y, o0, d0);
     double color[3] = {0, 0, 0};
-    int depth = sc->depth > ORC_MAX_DEPTH ? ORC_MAX_DEPTH : sc->depth;
     for (int s = 0; s < sc->spp; s++)
     {
-        uint32_t sample = (uint32_t)(sc->sample_offset + s);
-        double o[3] = {o0[0], o0[1], o0[2]}, d[3] = {d0[0], d0[1], d0[2]};
-        double D[ORC_MAX_DEPTH][3], C[ORC_MAX_DEPTH][3];
-        int len = 0;
-        double final[3] = {0, 0, 0};
-        if (st)
-            st->paths++;
-        for (int bounce = 0; bounce < depth; bounce++)
-        {
-            double p[3];
-            if (st)
-                st->segments++;
-            int32_t f = closest(sc, o, d, p, st);
-            int32_t mid;
-            if (f < 0 || (mid = sc->mat_ids[f]) == -1)
-            {
-                final[0] = final[1] = final[2] = 0;
-                break;
-            }
-            const double *mat_ = sc->mats + (size_t)mid * 12;
-            if (norm3(mat_) > 1e-6)
-            {
-                final[0] = mat_[0], final[1] = mat_[1], final[2] = mat_[2];
-                break;
-            }
-            const double *v = sc->verts + (size_t)f * 9;
-            double n[3];
-            if (sc->enable_bary_normal)
-            {
-                double w[3], acc[3] = {0, 0, 0};
-                const double *vn = sc->normals + (size_t)f * 9;
-                orc_barycentric(p, v, v + 3, v + 6, w);
-                for (int i = 0; i < 3; i++)
-                    for (int k = 0; k < 3; k++)
-                        acc[k] += w[i] * vn[i * 3 + k];
-                normalize3(acc, n);
-            }
-            else
-                orc_normal_from_3pts(v, v + 3, v + 6, n);
-
-            nee(sc, mat_, n, p, d, pixel, sample, (uint32_t)bounce, D[len], st);
-            if (sc->enable_indirect)
-            {
-                double wo[3] = {-d[0], -d[1], -d[2]}, wi[3], xi[2];
-                xi[0] = orc_rng(sc->seed, pixel, sample, (uint32_t)bounce, 4 * sc->n_lights + 0);
-                xi[1] = orc_rng(sc->seed, pixel, sample, (uint32_t)bounce, 4 * sc->n_lights + 1);
-                orc_bxdf_sample(mat_, n, wo, xi, wi, C[len]);
-                len++;
-                for (int i = 0; i < 3; i++)
-                    o[i] = p[i], d[i] = wi[i];
-            }
-            else
-            {
-                C[len][0] = C[len][1] = C[len][2] = 0;
-                len++;
-                break;
-            }
-        }
-        for (int i = len - 1; i >= 0; i--)
-        {
-            for (int k = 0; k < 3; k++)
-                final[k] = D[i][k] + C[i][k] * final[k];
-            double m = final[0];
-            if (final[1] > m)
-                m = final[1];
-            if (final[2] > m)
-                m = final[2];
-            if (0.0 > m)
-                m = 0.0; /* the 4th component is 0 and takes part in maxCoeff */
-            if (m > 1)
-                for (int k = 0; k < 3; k++)
-                    final[k] /= m;
-        }
+        double final[3];
+        trace_sample(sc, o0, d0, pixel, (uint32_t)(sc->sample_offset + s), final, st, NULL);
         for (int k = 0; k < 3; k++)
             color[k] += final[k] / sc->spp_total;
     }
     sum_out[0] = color[0], sum_out[1] = color[1], sum_out[2] = color[2];
+}
+
+/* One sample of one pixel with its diagnostics (tests only): rgb = the sample's radiance (not yet
+ * divided by the sample count); faces / margins: [depth] per-bounce face hit and winning margin.
+ * Returns the number of bounces traced. */
+int32_t orc_trace_sample(const orc_scene *sc, int x, int y, int sample, double *rgb, int32_t *faces,
+                         double *margins)
+{
+    double mat[16], o0[3], d0[3];
+    orc_probe pr;
+    orc_camera_matrix(sc, mat);
+    primary_ray(sc, mat, x, y, o0, d0);
+    trace_sample(sc, o0, d0, (uint32_t)(y * sc->width + x), (uint32_t)sample, rgb, NULL, &pr);
+    for (int i = 0; i < pr.n; i++)
+    {
+        if (faces)
+            faces[i] = pr.face[i];
+        if (margins)
+            margins[i] = pr.margin[i];
+    }
+    return pr.n;
 }
 
 /* the final per-pixel clamp (cPathTracer.cpp:701-702) */

@@ -239,6 +239,21 @@ def _stats_dict(st):
     return {f[0]: getattr(st, f[0]) for f in _lib.Stats._fields_}
 
 
+def render_sharded(contexts, scheme="bands", exchange="rccl", mode="f64", spp=None, spp_total=None, rows=None, band=8,
+                   depth=None, seed=13, batch_paths=None):
+    """One frame over several contexts (one per GPU, one host thread each inside the library) with
+    the final reduce of the radiance sums onto the first context's GPU: ptx_render_sharded.
+    scheme "samples" | "bands", exchange "rccl" | "peer".  Returns (sum [H,W,3], [stats per context])."""
+    ctxs = list(contexts)
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    o = ctxs[0]._opts(mode, spp, 0, spp_total, rows, 1, 0, band, depth, seed, batch_paths, False, False)
+    out = np.zeros((ctxs[0].height, ctxs[0].width, 3))
+    st = (_lib.Stats * len(ctxs))()
+    check(_lib.lib().ptx_render_sharded(arr, len(ctxs), C.byref(o), {"samples": 0, "bands": 1}[scheme],
+                                        {"rccl": 0, "peer": 1}[exchange], _ptr(out), st))
+    return out, [_stats_dict(x) for x in st]
+
+
 def finalize_image(img_sum):
     a = np.ascontiguousarray(img_sum, dtype=np.float64)
     out = np.zeros_like(a)

@@ -11,6 +11,7 @@
 #include <stdexcept>
 #include <algorithm>
 #include <string>
+#include <vector>
 
 struct ptx_scene
 {
@@ -494,11 +495,8 @@ int ptx_vistest(ptx_context *c, const double *p1, const double *p2, int64_t n, i
     PTX_CATCH
 }
 
-int ptx_render(ptx_context *c, const ptx_render_opts *o, double *rgb_sum, int32_t out_is_device, ptx_stats *stats)
+static ptx::RenderOpts to_opts(const ptx_render_opts *o)
 {
-    if (!c || !c->ctx || !rgb_sum)
-        return fail_arg("ptx_render: null argument");
-    PTX_TRY
     ptx::RenderOpts ro;
     if (o)
     {
@@ -512,19 +510,53 @@ int ptx_render(ptx_context *c, const ptx_render_opts *o, double *rgb_sum, int32_
         ro.accumulate = o->accumulate != 0;
         ro.profile = o->profile != 0;
     }
+    return ro;
+}
+
+static void from_stats(const ptx::RenderStats &st, ptx_stats *stats)
+{
+    stats->paths = st.paths, stats->segments = st.segments, stats->shadow_rays = st.shadow_rays;
+    stats->passes = st.passes;
+    stats->wave_iterations = st.wave_iterations;
+    stats->records = st.records;
+    stats->bvh_nodes = st.bvh_nodes, stats->bvh_tris = st.bvh_tris;
+    stats->ms_total = st.ms_total;
+    stats->ms_trace = st.ms_class[0], stats->ms_accumulate = st.ms_class[2];
+    stats->ms_other = st.ms_class[3];
+}
+
+int ptx_render(ptx_context *c, const ptx_render_opts *o, double *rgb_sum, int32_t out_is_device, ptx_stats *stats)
+{
+    if (!c || !c->ctx || !rgb_sum)
+        return fail_arg("ptx_render: null argument");
+    PTX_TRY
     ptx::RenderStats st;
-    c->ctx->render(ro, rgb_sum, out_is_device != 0, st);
+    c->ctx->render(to_opts(o), rgb_sum, out_is_device != 0, st);
     if (stats)
+        from_stats(st, stats);
+    PTX_CATCH
+}
+
+int ptx_render_sharded(ptx_context *const *contexts, int32_t n, const ptx_render_opts *o, int32_t scheme, int32_t exchange,
+                       double *rgb_sum, ptx_stats *stats)
+{
+    if (!contexts || n < 1 || !rgb_sum)
+        return fail_arg("ptx_render_sharded: null argument or no context");
+    if ((scheme != PTX_SHARD_SAMPLES && scheme != PTX_SHARD_BANDS) || (exchange != PTX_EXCHANGE_RCCL && exchange != PTX_EXCHANGE_PEER))
+        return fail_arg("ptx_render_sharded: unknown scheme or exchange");
+    PTX_TRY
+    std::vector<ptx::Context *> cs(n);
+    for (int i = 0; i < n; i++)
     {
-        stats->paths = st.paths, stats->segments = st.segments, stats->shadow_rays = st.shadow_rays;
-        stats->passes = st.passes;
-        stats->wave_iterations = st.wave_iterations;
-        stats->records = st.records;
-        stats->bvh_nodes = st.bvh_nodes, stats->bvh_tris = st.bvh_tris;
-        stats->ms_total = st.ms_total;
-        stats->ms_trace = st.ms_class[0], stats->ms_accumulate = st.ms_class[2];
-        stats->ms_other = st.ms_class[3];
+        if (!contexts[i] || !contexts[i]->ctx)
+            throw std::runtime_error("arg: ptx_render_sharded: null context");
+        cs[i] = contexts[i]->ctx;
     }
+    std::vector<ptx::RenderStats> st(n);
+    ptx::render_sharded(cs.data(), n, to_opts(o), scheme, exchange, rgb_sum, st.data());
+    if (stats)
+        for (int i = 0; i < n; i++)
+            from_stats(st[i], &stats[i]);
     PTX_CATCH
 }
 

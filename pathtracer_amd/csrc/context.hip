@@ -376,6 +376,11 @@ void Context::build_accel(const Scene &sc)
 {
     HIP_CHECK(hipSetDevice(device_));
     hipStream_t s = static_cast<hipStream_t>(stream_);
+    // a build that fails half way leaves the context without a scene (the host copy below and the
+    // device tables of the previous scene would not belong together)
+    have_scene_ = false;
+    if (sc.lights.size() > 16383)
+        throw std::runtime_error("arg: at most 16383 lights are supported (dimension field of the random-number counter)");
     scene_ = sc; // host copy (camera, tracer settings)
     // all-triangles intersector: small scenes whose plane records fit the candidate mask
     PlaneRecords pr;

@@ -73,6 +73,8 @@ public:
     size_t stack_bytes() const { return brute_ ? 0 : static_cast<size_t>(bvh_.stack_need > 1 ? bvh_.stack_need : 1) * 256 * 4; }
     const Scene &scene() const { return scene_; }
     bool has_scene() const { return have_scene_; }
+    int device() const { return device_; }
+    void *stream() const { return stream_; }
 
     // scenes up to this many triangles are intersected by the all-triangles loop
     int brute_force_limit = 64;
@@ -109,5 +111,9 @@ private:
     Impl<float> *f32_ = nullptr;
     RenderTimers timers_;
 };
+
+// One frame over n contexts (one per GPU, one host thread each) and the final reduce of the sums
+// onto context 0's GPU; scheme / exchange: PTX_SHARD_* / PTX_EXCHANGE_* of ptx.h (sharded.hip)
+void render_sharded(Context *const *ctxs, int n, const RenderOpts &base, int scheme, int exchange, double *rgb_sum, RenderStats *stats);
 
 } // namespace ptx

@@ -102,15 +102,22 @@ __host__ __device__ __forceinline__ uint64_t rng_pixel_key(uint64_t seed, uint32
 {
     return mix64(seed + 0x9E3779B97F4A7C15ULL * (uint64_t(pixel) + 1));
 }
+// counter word of one draw: sample in the high half; below it the dimension's high byte (bits
+// 24-31), the bounce (bits 8-23, at most 65535) and the dimension's low byte -- distinct for every
+// (sample, bounce < 2^16, dimension < 2^16), i.e. for up to 16 383 lights
+__host__ __device__ __forceinline__ uint64_t rng_counter(uint32_t s, uint32_t b, uint32_t d)
+{
+    return (uint64_t(s) << 32) | (uint64_t(d >> 8) << 24) | (uint64_t(b) << 8) | uint64_t(d & 255u);
+}
 template <class R> __device__ __forceinline__ R rng_draw(uint64_t pixel_key, uint32_t sample, uint32_t bounce, uint32_t dim);
 template <> __device__ __forceinline__ double rng_draw<double>(uint64_t k, uint32_t s, uint32_t b, uint32_t d)
 {
-    uint64_t h = mix64(k ^ ((uint64_t(s) << 32) | (uint64_t(b) << 8) | uint64_t(d)));
+    uint64_t h = mix64(k ^ rng_counter(s, b, d));
     return double(h >> 11) * (1.0 / 9007199254740992.0);
 }
 template <> __device__ __forceinline__ float rng_draw<float>(uint64_t k, uint32_t s, uint32_t b, uint32_t d)
 {
-    uint64_t h = mix64(k ^ ((uint64_t(s) << 32) | (uint64_t(b) << 8) | uint64_t(d)));
+    uint64_t h = mix64(k ^ rng_counter(s, b, d));
     return float(h >> 40) * (1.0f / 16777216.0f);
 }
 

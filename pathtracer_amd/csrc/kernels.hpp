@@ -500,8 +500,11 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
 
 // closest hit.  Returns the intersector-order triangle index (or -1) and the hit point.
 // Winner = smallest |p - o| among accepted hits with |p - o| > self_eps; ties -> lowest face id.
+// The culling side (plane records, box slabs) measures along `du`, the direction at unit length,
+// so that its bounds are in the units of the winner's distance |p - o|; the exact test runs on the
+// ray (o, d) as given, whatever the length of d (the tracer's rays are unit length: du = d).
 template <class R, bool BRUTE>
-__device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d, V3<R> &pt, int *stk, int skip = -1)
+__device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d, V3<R> du, V3<R> &pt, int *stk, int skip = -1)
 {
     R best = Consts<R>::big;
     int target = -1;
@@ -511,8 +514,8 @@ __device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d,
         const BruteLds<R> *L = reinterpret_cast<const BruteLds<R> *>(stk);
         int near_rec;
         unsigned long long mask =
-            prefilter_mask<true>(S.tri_pq, S.n_recs, S.pq_smax, o, d, float(self_eps) * 0.9f, __builtin_inff(), 0xFFFFFFFFu, near_rec);
-        mask = drop_own_plane(mask, L, skip, d);
+            prefilter_mask<true>(S.tri_pq, S.n_recs, S.pq_smax, o, du, float(self_eps) * 0.9f, __builtin_inff(), 0xFFFFFFFFu, near_rec);
+        mask = drop_own_plane(mask, L, skip, du);
         auto exact = [&](int bit) {
             const int f = L->rec_tri[bit];
             R t;
@@ -545,7 +548,7 @@ __device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d,
         // of the plane normals, with the error bound of the prefilter
         if (target >= 0)
         {
-            const float ox = float(o.x), oy = float(o.y), oz = float(o.z), dx = float(d.x), dy = float(d.y), dz = float(d.z);
+            const float ox = float(o.x), oy = float(o.y), oz = float(o.z), dx = float(du.x), dy = float(du.y), dz = float(du.z);
             const float Tmax = 1.75f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + S.pq_smax;
             const float bound = float(best) * 1.000001f + 1e-30f;
             unsigned long long rest = mask;
@@ -572,7 +575,7 @@ __device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d,
     }
     Trav<R> T;
     uint32_t visits[2] = {0, 0};
-    trav_init(T, o, d);
+    trav_init(T, o, du); // slab distances along the unit direction: same units as T.best
     while (bvh_step<R, false>(S, o, d, T, stk, visits))
     {
     }
@@ -676,7 +679,8 @@ __global__ void __launch_bounds__(BLOCK)
         d = {R(rd[i * 3]), R(rd[i * 3 + 1]), R(rd[i * 3 + 2])};
     }
     V3<R> p = {R(0), R(0), R(0)};
-    int k = closest_hit<R, BRUTE>(S, o, d, p, stk);
+    // cAccelStruct::RayCast takes a direction of any length (tRay::Init does not normalise)
+    int k = closest_hit<R, BRUTE>(S, o, d, from_camera ? d : normalized(d), p, stk);
     face_ids[i] = k < 0 ? -1 : S.tri_face[k];
     if (pts)
     {
@@ -1067,7 +1071,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         {
             n_seg++;
             if constexpr (BRUTE)
-                hit_k = closest_hit<R, BRUTE>(S, o, d, p, stk, prim);
+                hit_k = closest_hit<R, BRUTE>(S, o, d, d, p, stk, prim);
             else
                 hit_k = T.target, p = o + T.best_t * d;
             int mat_id = -1;

@@ -21,7 +21,9 @@ int main(int argc, char **argv)
     if (argc < 2)
     {
         std::printf("[error] usage: pathtracer <conf> [--width W] [--height H] [--spp N] [--depth D] [--out PATH] "
-                    "[--mode f64|f32] [--gpu ID] [--seed S] [--root DIR] [--model OBJ]\n");
+                    "[--mode f64|f32] [--gpu ID] [--seed S] [--root DIR] [--model OBJ]\n"
+                    "        several GPUs of this node: [--gpus N | --devices ID,ID,...] [--scheme bands|samples] "
+                    "[--exchange rccl|peer]\n");
         return 1;
     }
     ptx_overrides ov;
@@ -31,6 +33,8 @@ int main(int argc, char **argv)
     ro.seed = 13;
     std::string out_path, root;
     int gpu = 0;
+    std::vector<int> devices; // more than one entry: the frame is sharded over these GPUs
+    int scheme = PTX_SHARD_BANDS, exchange = PTX_EXCHANGE_RCCL;
     for (int i = 2; i < argc; i++)
     {
         std::string a = argv[i];
@@ -51,6 +55,29 @@ int main(int argc, char **argv)
             ov.model = next();
         else if (a == "--gpu")
             gpu = std::atoi(next());
+        else if (a == "--gpus")
+        {
+            devices.clear();
+            for (int k = 0, n = std::atoi(next()); k < n; k++)
+                devices.push_back(k);
+        }
+        else if (a == "--devices")
+        {
+            devices.clear();
+            std::string list = next();
+            for (size_t p = 0; p < list.size();)
+            {
+                size_t q = list.find(',', p);
+                if (q == std::string::npos)
+                    q = list.size();
+                devices.push_back(std::atoi(list.substr(p, q - p).c_str()));
+                p = q + 1;
+            }
+        }
+        else if (a == "--scheme")
+            scheme = std::string(next()) == "samples" ? PTX_SHARD_SAMPLES : PTX_SHARD_BANDS;
+        else if (a == "--exchange")
+            exchange = std::string(next()) == "peer" ? PTX_EXCHANGE_PEER : PTX_EXCHANGE_RCCL;
         else if (a == "--seed")
             ro.seed = std::strtoull(next(), nullptr, 10);
         else if (a == "--mode")
@@ -68,15 +95,40 @@ int main(int argc, char **argv)
     ptx_scene_get_info(scene, &info);
     std::printf("[log] scene: %d faces, %d materials, %d lights, %dx%d, %d spp, depth %d\n", info.n_tris, info.n_mats,
                 info.n_lights, info.width, info.height, info.spp, info.depth);
-    ptx_context *ctx = nullptr;
-    if (ptx_context_create(gpu, &ctx))
-        return die("create context");
-    if (ptx_build_accel(ctx, scene))
-        return die("build accel");
+    if (devices.empty())
+        devices.push_back(gpu);
+    // one context per GPU, each with its own copy of the scene
+    std::vector<ptx_context *> ctxs(devices.size(), nullptr);
+    for (size_t k = 0; k < devices.size(); k++)
+    {
+        if (ptx_context_create(devices[k], &ctxs[k]))
+            return die("create context");
+        if (ptx_build_accel(ctxs[k], scene))
+            return die("build accel");
+    }
+    ptx_context *ctx = ctxs[0];
     std::vector<double> sum(static_cast<size_t>(info.width) * info.height * 3), img(sum.size());
     ptx_stats st;
-    if (ptx_render(ctx, &ro, sum.data(), 0, &st))
-        return die("render");
+    if (ctxs.size() == 1)
+    {
+        if (ptx_render(ctx, &ro, sum.data(), 0, &st))
+            return die("render");
+    }
+    else
+    {
+        // interleaved row bands of 8 (or sample ranges), one host thread per GPU inside the library,
+        // then the one exchange: the per-pixel sums reduced onto the first GPU
+        std::vector<ptx_stats> per(ctxs.size());
+        if (ptx_render_sharded(ctxs.data(), static_cast<int32_t>(ctxs.size()), &ro, scheme, exchange, sum.data(), per.data()))
+            return die("sharded render");
+        std::memset(&st, 0, sizeof(st));
+        for (size_t k = 0; k < per.size(); k++)
+        {
+            std::printf("[log] gpu %d: %llu paths, %.3f ms\n", devices[k], (unsigned long long)per[k].paths, per[k].ms_total);
+            st.paths += per[k].paths, st.segments += per[k].segments, st.shadow_rays += per[k].shadow_rays;
+            st.ms_total = per[k].ms_total > st.ms_total ? per[k].ms_total : st.ms_total; // the GPUs run side by side
+        }
+    }
     std::printf("[log] cPathTracer::RayCast end, cost time = %.3f ms, %.3f Mpaths/s, %.3f Mrays/s\n", st.ms_total,
                 st.paths / st.ms_total * 1e-3, (st.segments + st.shadow_rays) / st.ms_total * 1e-3);
     ptx_finalize_image(sum.data(), static_cast<int64_t>(info.width) * info.height, img.data());
@@ -85,7 +137,8 @@ int main(int argc, char **argv)
     if (ptx_write_ppm(out_path.c_str(), img.data(), info.width, info.height))
         return die("write ppm");
     std::printf("[debug] output img to %s, finished\n", out_path.c_str());
-    ptx_context_destroy(ctx);
+    for (ptx_context *c : ctxs)
+        ptx_context_destroy(c);
     ptx_scene_destroy(scene);
     return 0;
 }

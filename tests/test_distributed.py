@@ -65,3 +65,42 @@ def test_two_ranks_reproduce_the_single_process_frame(scheme):
     mp.spawn(_worker, args=(2, port, scheme, ret), nprocs=2, join=True)
     # sample ranges: sums re-associated across ranks -> 1 ulp; bands: exact union
     assert ret["max_diff"] <= (1e-14 if scheme == "samples" else 0.0)
+
+
+@pytest.mark.parametrize("scheme", ["samples", "bands"])
+def test_bench_starts_its_own_ranks(scheme):
+    """`python bench.py --gpus 2` as the driver invokes it -- no launcher, WORLD_SIZE unset -- starts
+    two ranks itself, and rank 0's line comes back through the parent with the world size the
+    process group saw.  Rehearsed on the CPU: gloo, the oracle as the render function."""
+    import json
+    import subprocess
+
+    from oracle import oracle, scene_io
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["PYTHONPATH"] = os.path.join(ROOT, "tests") + os.pathsep + env.get("PYTHONPATH", "")
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "24",
+           "--spp", "3", "--scheme", scheme, "--rehearse", "bench_rehearsal"]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1                                  # ONE line on stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["warmup"] == 1 and res["value"] > 0
+    assert res["scaling"] == ("weak" if scheme == "samples" else "strong")
+    total = 6 if scheme == "samples" else 3                 # weak scaling: 3 spp per rank
+    assert res["config"]["global_spp"] == total
+    sc = scene_io.load_conf(os.path.join(ROOT, "config/cbox.conf"), root_dir=ROOT, width=24, height=24, spp=total)
+    full = oracle.Oracle(sc, seed=13).render(threads=1)
+    assert abs(res["frame_checksum"] - float(full.sum())) <= 1e-10
+
+
+def test_bench_reports_failing_ranks():
+    """A rank that dies takes the parent's exit status with it (no result line)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "8",
+           "--spp", "1", "--rehearse", "no_such_module"]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert proc.returncode != 0 and proc.stdout.strip() == ""

@@ -1,0 +1,100 @@
+"""The benchmark configurations at their own sizes, through the C ABI (run on an MI355X with -m gpu):
+config/mis.conf at its native 768 x 512 and config/room.conf at 3840 x 2160, the frame the 8-GPU
+configuration shards.  At these sizes the checks are properties that need no full CPU render --
+the cuts a multi-GPU run makes of the frame (interleaved row bands of 8 over 8 phases, 8 sample
+ranges) add up to the frame rendered in one piece -- plus the oracle on the first-hit ids of the
+whole frame and on windows of the image."""
+import os
+
+import numpy as np
+import pytest
+
+import pathtracer_amd as pt
+from oracle import oracle, scene_io
+from test_gpu_parity import assert_f64_parity, load, make_ctx
+
+pytestmark = pytest.mark.gpu
+
+
+def cuts_add_up(c, spp, ranks=8, band=8):
+    """The two ways a frame is cut across `ranks` GPUs, replayed on one: row bands (disjoint rows,
+    so the sum of the parts IS the frame, bit for bit) and sample ranges (accumulated in rank order
+    the running sums continue exactly; summed as separate images they agree to an ulp)."""
+    full, st = c.render(mode="f64", spp=spp)
+    acc = np.zeros_like(full)
+    rows = np.arange(full.shape[0])
+    segs = 0
+    for k in range(ranks):
+        part, sp = c.render(mode="f64", spp=spp, row_stride=ranks, row_phase=k, band=band)
+        assert (part[(rows // band) % ranks != k] == 0).all()          # nothing outside this rank's bands
+        acc += part
+        segs += sp["segments"]
+    assert np.array_equal(acc, full) and segs == st["segments"]
+    per = spp // ranks
+    run = np.zeros_like(full)
+    tot = np.zeros_like(full)
+    for k in range(ranks):
+        run, _ = c.render(mode="f64", spp=per, sample_offset=k * per, spp_total=spp, accumulate=True, out=run)
+        one, _ = c.render(mode="f64", spp=per, sample_offset=k * per, spp_total=spp)
+        tot += one
+    assert np.array_equal(run, full)
+    assert np.abs(tot - full).max() <= 4e-16 * max(1.0, float(full.max()))
+    return full, st
+
+
+def test_mis_at_native_size(root):
+    """config/mis.conf, 768 x 512 (its own size), depth 5, five sphere lights: the whole f64 image
+    against the oracle at equal spp, first-hit ids of every pixel, and the cuts."""
+    s, ref = load(root, "config/mis.conf", spp=8)
+    assert (ref.width, ref.height) == (768, 512)
+    c, O = make_ctx(s), oracle.Oracle(ref, seed=13)
+    assert not c.accel_info()["brute_force"]
+    full, st = cuts_add_up(c, 8)
+    ids, pts = c.first_hit(with_points=True)
+    oids, opts = O.first_hit(with_points=True)
+    assert int((ids != oids).sum()) == 0 and np.array_equal(pts, opts, equal_nan=True)
+    oimg, ost = O.render(stats=True)
+    assert_f64_parity(full, oimg, st, ost, depth=ref.depth, ctx=c, O=O)
+    f32, _ = c.render(mode="f32", spp=8)
+    assert oracle.rmse_rel(f32, oimg) < 1e-3
+    assert (full[(ids == -1).reshape(512, 768)] == 0).all()
+
+
+def test_room_at_3840x2160(root, room_scene):
+    """config/room.conf at 3840 x 2160 (336 k triangles, BVH, ring tracer): the frame of the 8-GPU
+    configuration.  Bands and sample ranges add up; first-hit ids of all 8.3 M pixels equal the
+    oracle's; two windows of the image equal the oracle rendering only those windows."""
+    W, H, spp = 3840, 2160, 8
+    s, ref = load(root, "config/room.conf", width=W, height=H, spp=spp)
+    ref.use_bvh = True
+    c = make_ctx(s)
+    assert not c.accel_info()["brute_force"]
+    full, st = cuts_add_up(c, spp)
+    assert st["paths"] == W * H * spp
+    O = oracle.Oracle(ref, seed=13)
+    ids = c.first_hit()
+    assert int((ids != O.first_hit()).sum()) == 0
+    assert (full[(ids == -1).reshape(H, W)] == 0).all()
+    for r0, c0, nr, nc in ((1200, 1500, 8, 160), (400, 2900, 6, 96)):
+        ref.region = (r0, c0, r0 + nr - 1, c0 + nc - 1)
+        Ow = oracle.Oracle(ref, seed=13)
+        oimg = Ow.render()
+        assert_f64_parity(full[r0:r0 + nr, c0:c0 + nc], oimg[r0:r0 + nr, c0:c0 + nc], depth=ref.depth, ctx=c, O=Ow,
+                          origin=(r0, c0))
+    f32, _ = c.render(mode="f32", spp=spp)
+    assert oracle.rmse_rel(f32, full) < 1e-3
+
+
+def test_cbox_headline_config_window_and_ids(root):
+    """config/cbox.conf at 1024 x 1024 with the 256 spp of the headline configuration, on a row
+    band (rendering all rows at 256 spp on the CPU takes minutes): the band against the oracle, the
+    ids of the whole frame."""
+    s, ref = load(root, "config/cbox.conf", width=1024, height=1024, spp=256)
+    c = make_ctx(s)
+    band, st = c.render(mode="f64", rows=(508, 510))
+    ref.region = (508, 0, 509, 1023)
+    O = oracle.Oracle(ref, seed=13)
+    oimg, ost = O.render(stats=True)
+    assert st["paths"] == 2 * 1024 * 256
+    assert_f64_parity(band[508:510], oimg[508:510], st, ost, ctx=c, O=O, origin=(508, 0))
+    assert (band[:508] == 0).all() and (band[510:] == 0).all()

@@ -1,0 +1,66 @@
+"""ptx_render_sharded and the command line's --devices: one frame over several contexts driven by
+host threads inside the library, and the final exchange.  A one-GPU box can run several contexts on
+its one GPU with the peer-copy exchange (same threads, same cuts, same ordered sum) and RCCL with a
+communicator of one; RCCL between GPUs needs a node with more than one."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pathtracer_amd as pt
+from test_gpu_parity import load, make_ctx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("conf,kw", [("config/cbox.conf", dict(width=96, height=80, spp=7)),
+                                     ("config/mis.conf", dict(width=96, height=64, spp=5))])
+def test_sharded_render_equals_single_render(root, conf, kw):
+    s, _ = load(root, conf, **kw)
+    ctxs = [make_ctx(s) for _ in range(3)]
+    full, st = ctxs[0].render(mode="f64")
+    bands, sb = pt.render_sharded(ctxs, scheme="bands", exchange="peer", band=8)
+    assert np.array_equal(bands, full)                               # disjoint rows: the frame, bit for bit
+    assert sum(x["paths"] for x in sb) == st["paths"] and sum(x["segments"] for x in sb) == st["segments"]
+    assert all(x["paths"] > 0 for x in sb)
+    samples, ss = pt.render_sharded(ctxs, scheme="samples", exchange="peer")
+    assert [x["paths"] for x in ss] == [kw["width"] * kw["height"] * n for n in
+                                        (kw["spp"] // 3 + (kw["spp"] % 3 > 0), kw["spp"] // 3 + (kw["spp"] % 3 > 1), kw["spp"] // 3)]
+    assert np.abs(samples - full).max() <= 1e-14 * max(1.0, full.max())
+    # more contexts than samples: the idle ones contribute zeros
+    two, s2 = pt.render_sharded(ctxs, scheme="samples", exchange="peer", spp=2)
+    ref2, _ = ctxs[0].render(mode="f64", spp=2)
+    assert s2[2]["paths"] == 0 and np.abs(two - ref2).max() <= 1e-14 * max(1.0, ref2.max())
+    f32, _ = pt.render_sharded(ctxs[:2], scheme="bands", exchange="peer", mode="f32")
+    assert np.array_equal(f32, ctxs[0].render(mode="f32")[0])
+
+
+def test_rccl_exchange_with_a_communicator_of_one(root):
+    s, _ = load(root, "config/cbox.conf", width=64, height=64, spp=4)
+    c = make_ctx(s)
+    full, _ = c.render(mode="f64")
+    for scheme in ("bands", "samples"):
+        img, st = pt.render_sharded([c], scheme=scheme, exchange="rccl")
+        assert np.array_equal(img, full)
+    with pytest.raises(pt.PtxError) as e:
+        pt.render_sharded([c, make_ctx(s)], exchange="rccl")          # two contexts on one GPU: not a communicator
+    assert e.value.code == 1
+
+
+def test_command_line_shards_over_devices(root, tmp_path):
+    exe = os.path.join(root, "pathtracer_amd", "pathtracer")
+    base = [exe, "config/cbox.conf", "--width", "72", "--height", "56", "--spp", "5"]
+    outs = {}
+    for name, extra in (("one", []), ("bands", ["--devices", "0,0,0", "--exchange", "peer"]),
+                        ("samples", ["--devices", "0,0", "--exchange", "peer", "--scheme", "samples"]),
+                        ("rccl1", ["--gpus", "1"])):
+        out = tmp_path / (name + ".ppm")
+        p = subprocess.run(base + extra + ["--out", str(out)], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, timeout=300)
+        assert p.returncode == 0, p.stdout
+        outs[name] = pt.read_ppm(str(out))
+    assert np.array_equal(outs["one"], outs["bands"]) and np.array_equal(outs["one"], outs["rccl1"])
+    assert np.abs(outs["one"] - outs["samples"]).max() <= 1            # int(c * 255) of sums that differ by an ulp
+    p = subprocess.run(base + ["--devices", "0,7"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 1 and "[error]" in p.stdout                  # the reference's error convention
