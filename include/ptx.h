@@ -81,6 +81,8 @@ typedef struct ptx_stats
     double ms_total;        /* device time of the call, HIP events on the context's stream       */
     double ms_trace, ms_accumulate, ms_other; /* per-kernel device time (profiling
                                mode only, otherwise 0)                                           */
+    uint64_t state_bytes;   /* device memory the call's path state took (record slots of the
+                               tracer's waves, per-path results of a batch, rings, stack spill)  */
 } ptx_stats;
 
 /* ---- scene front end ----------------------------------------------------------------------
@@ -172,6 +174,12 @@ int ptx_render(ptx_context *, const ptx_render_opts *, double *rgb_sum, int32_t 
 int ptx_raycast(ptx_context *, const double *rays_o, const double *rays_d, int64_t n,
                 int32_t *face_ids, double *hit_pts);
 int ptx_vistest(ptx_context *, const double *p1, const double *p2, int64_t n, int32_t *visible);
+/* Name of the tracer kernel the last ptx_render / ptx_render_static of this context launched, as
+ * a profiler prints it ("k_trace_f64<true, true, 1>", "k_trace_rings_f64<true, false>", ...); ""
+ * before the first render.  No counterpart in the reference; measurement tooling uses it to tie
+ * counter profiles to the kernel that actually ran. */
+const char *ptx_context_last_kernel(const ptx_context *);
+
 
 /* ---- one frame over several GPUs of one node ---------------------------------------------------
  * ptx_render_sharded shards the row loop of cPathTracer::RayTracing (src/tracing/cPathTracer.cpp:

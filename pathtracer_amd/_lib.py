@@ -41,7 +41,7 @@ class RenderOpts(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("passes", C.c_uint64), ("wave_iterations", C.c_uint64), ("records", C.c_uint64), ("bvh_nodes", C.c_uint64), ("bvh_tris", C.c_uint64), ("ms_total", C.c_double), ("ms_trace", C.c_double),
-                ("ms_accumulate", C.c_double), ("ms_other", C.c_double)]
+                ("ms_accumulate", C.c_double), ("ms_other", C.c_double), ("state_bytes", C.c_uint64)]
 
 
 # every symbol include/ptx.h declares: name -> (restype, argtypes)
@@ -69,6 +69,7 @@ SYMBOLS = {
     "ptx_generate_rays": (C.c_int, [_VP, _VP, _VP]),
     "ptx_first_hit": (C.c_int, [_VP, _VP, _VP]),
     "ptx_render": (C.c_int, [_VP, C.POINTER(RenderOpts), _VP, C.c_int32, C.POINTER(Stats)]),
+    "ptx_context_last_kernel": (C.c_char_p, [_VP]),
     "ptx_render_sharded": (C.c_int, [_VP, C.c_int32, C.POINTER(RenderOpts), C.c_int32, C.c_int32, _VP, _VP]),
     "ptx_raycast": (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP]),
     "ptx_vistest": (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP]),

@@ -235,6 +235,10 @@ class Context:
         return _stats_dict(st)
 
 
+    def last_kernel(self):
+        return _lib.lib().ptx_context_last_kernel(self._h).decode()
+
+
 def _stats_dict(st):
     return {f[0]: getattr(st, f[0]) for f in _lib.Stats._fields_}
 

@@ -36,8 +36,8 @@ constexpr int RING_TESTS_SHIFT = 16, RING_RESULT_SHIFT = 20, RING_MAX_TESTS = 12
 constexpr int RING_BATCH = 40;      // lanes that hand over hits / take rays together (a hand-over drains the
                                     // wave's outstanding loads; measured plateau: 32 to 48)
 
-// bytes of one wave's two rings
-template <class R> constexpr size_t ring_bytes() { return size_t(RING_CAP) * (12 * sizeof(R) + 4 * 11); }
+// bytes of one wave's two rings and of its stack of free record slots
+template <class R> constexpr size_t ring_bytes() { return size_t(RING_CAP) * (12 * sizeof(R) + 4 * 13) + size_t(RING_SLOTS) * 4; }
 
 // views of the two rings of one wave (structure of arrays: one field of 256 entries after the other)
 template <class R> struct Rings
@@ -51,6 +51,8 @@ template <class R> struct Rings
     R *hp, *hd;        // [3][CAP]: hit point, ray direction
     int32_t *h_tri;
     uint32_t *h_pid, *h_bounce, *h_klo, *h_khi; // h_bounce: state word
+    uint32_t *r_slot, *h_slot; // the record slot the entry's path holds
+    uint32_t *free_slot;       // [RING_SLOTS] stack of the record slots no path holds
     __device__ explicit Rings(void *base)
     {
         R *f = reinterpret_cast<R *>(base);
@@ -61,6 +63,8 @@ template <class R> struct Rings
         h_pid = u + 5 * RING_CAP, h_bounce = u + 6 * RING_CAP, h_klo = u + 7 * RING_CAP, h_khi = u + 8 * RING_CAP;
         r_tri = reinterpret_cast<int32_t *>(u + 9 * RING_CAP);
         r_light = reinterpret_cast<int32_t *>(u + 10 * RING_CAP);
+        r_slot = u + 11 * RING_CAP, h_slot = u + 12 * RING_CAP;
+        free_slot = u + 13 * RING_CAP;
     }
 };
 
@@ -107,6 +111,12 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     DoneQueue &dq = done_queues[threadIdx.x >> 6];
     uint32_t dq_head = 0, dq_count = 0;               // wave-uniform
     uint32_t rq_head = 0, rq_count = 0, hq_head = 0, hq_count = 0; // wave-uniform
+    // record slots: a path takes one when its camera ray is admitted and returns it in its resolve
+    // pass; at most 192 paths are in flight and at most 127 wait in dq, so the stack never runs dry
+    for (int k = lane; k < RING_SLOTS; k += 64)
+        Q.free_slot[k] = uint32_t(k);
+    uint32_t free_count = RING_SLOTS; // wave-uniform
+    uint32_t slot = 0;                // of the path whose ray this lane traverses
 
     // the ray this lane is traversing
     bool busy = false, done = false; // done: traversal complete, the hit waits to be handed over
@@ -127,6 +137,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
         const uint32_t e = (dq_head + uint32_t(lane)) % DoneQueue::CAP;
         const bool mine = uint32_t(lane) < n;
         const uint32_t rp = mine ? dq.pid[e] : 0u, rs = mine ? dq.state[e] : 0u;
+        const uint32_t rslot = mine ? uint32_t(dq.slot[e]) : 0u;
         const int len = int(rs >> 16), tm = int(rs & 0xffffu);
         R fr = R(0), fg = R(0), fb = R(0);
         if (tm)
@@ -141,7 +152,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
         int wlen = len;
         for (int off = 32; off > 0; off >>= 1)
             wlen = max(wlen, __shfl_xor(wlen, off, 64));
-        const R *rec = st.stack + (size_t)rp * depth * 6;
+        const R *rec = record_at(st, g, rslot, depth, 0u);
         constexpr int G = 2; // levels whose loads are in flight together
         for (int top = wlen - 1; top >= 0; top -= G)
         {
@@ -153,7 +164,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 const bool on = i >= 0 && i < len;
                 q[k][0] = q[k][1] = q[k][2] = q[k][3] = q[k][4] = q[k][5] = R(0);
                 if (on) // lanes whose stack is shorter do not touch memory
-                    load_record(rec + i * 6, q[k]); // 48 (24) bytes in 3 loads
+                    load_record(rec + i * REC_STRIDE, q[k]); // 48 (24) bytes in 3 (2) loads
             }
 #pragma unroll
             for (int k = 0; k < G; k++)
@@ -180,7 +191,11 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             }
         }
         if (mine)
+        {
             st.result[rp] = fr, st.result[st.N + rp] = fg, st.result[2 * st.N + rp] = fb;
+            Q.free_slot[free_count + uint32_t(lane)] = rslot; // the slots go back on the stack
+        }
+        free_count += n;
         dq_head = (dq_head + n) % DoneQueue::CAP;
         dq_count -= n;
     };
@@ -196,14 +211,14 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
         uint32_t defer_state = 0;
         uint32_t fin_state = 0;
         V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)}, keep_d = {R(0), R(0), R(0)};
-        uint32_t s_pid = 0, s_bounce = 0, s_klo = 0, s_khi = 0;
+        uint32_t s_pid = 0, s_bounce = 0, s_klo = 0, s_khi = 0, s_slot = 0;
         int keep_tri = -1;
         if (mine)
         {
             p = {Q.hp[e], Q.hp[RING_CAP + e], Q.hp[2 * RING_CAP + e]};
             const V3<R> sd = {Q.hd[e], Q.hd[RING_CAP + e], Q.hd[2 * RING_CAP + e]};
             const int hit_k = Q.h_tri[e];
-            s_pid = Q.h_pid[e], s_bounce = Q.h_bounce[e], s_klo = Q.h_klo[e], s_khi = Q.h_khi[e];
+            s_pid = Q.h_pid[e], s_bounce = Q.h_bounce[e], s_klo = Q.h_klo[e], s_khi = Q.h_khi[e], s_slot = Q.h_slot[e];
             const uint32_t state = s_bounce;
             const int tested = int((state >> RING_TESTS_SHIFT) & 15u); // visibility tests of this bounce already done
             s_bounce &= RING_BOUNCE;
@@ -299,9 +314,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                         const R x2 = rng_draw<R>(key, sample, bnc, 4 * S.n_lights + 1);
                         bxdf_sample(m, nrm, wo, x1, x2, wi, coef);
                     }
-                    R *rec = st.stack + ((size_t)s_pid * depth + bnc) * 6;
-                    rec[0] = direct.x, rec[1] = direct.y, rec[2] = direct.z;
-                    rec[3] = coef.x, rec[4] = coef.y, rec[5] = coef.z;
+                    store_record(record_at(st, g, s_slot, depth, uint32_t(bnc)), direct, coef);
                     n_rec++;
                     if (S.enable_indirect && bnc + 1 < depth)
                         cont = true;
@@ -325,7 +338,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 Q.ro[r] = p.x, Q.ro[RING_CAP + r] = p.y, Q.ro[2 * RING_CAP + r] = p.z;
                 Q.rd[r] = od.x, Q.rd[RING_CAP + r] = od.y, Q.rd[2 * RING_CAP + r] = od.z;
                 Q.r_pid[r] = s_pid, Q.r_bounce[r] = defer ? defer_state : s_bounce + 1u;
-                Q.r_klo[r] = s_klo, Q.r_khi[r] = s_khi;
+                Q.r_klo[r] = s_klo, Q.r_khi[r] = s_khi, Q.r_slot[r] = s_slot;
                 if (SQ)
                     Q.r_tri[r] = keep_tri, Q.r_light[r] = defer ? defer_light : -1;
             }
@@ -337,7 +350,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             if (finished)
             {
                 const uint32_t r = (dq_head + dq_count + rank_in(fm)) % DoneQueue::CAP;
-                dq.pid[r] = s_pid, dq.state[r] = fin_state, dq.need[r] = 0u;
+                dq.pid[r] = s_pid, dq.state[r] = fin_state, dq.need[r] = 0u, dq.slot[r] = uint16_t(s_slot);
             }
             dq_count += uint32_t(__popcll(fm));
             if (dq_count >= 64u)
@@ -383,7 +396,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 Q.hp[r] = p.x, Q.hp[RING_CAP + r] = p.y, Q.hp[2 * RING_CAP + r] = p.z;
                 Q.hd[r] = hd.x, Q.hd[RING_CAP + r] = hd.y, Q.hd[2 * RING_CAP + r] = hd.z;
                 Q.h_tri[r] = test ? vtri : T.target;
-                Q.h_pid[r] = pid, Q.h_klo[r] = klo, Q.h_khi[r] = khi;
+                Q.h_pid[r] = pid, Q.h_klo[r] = klo, Q.h_khi[r] = khi, Q.h_slot[r] = slot;
                 // a test adds its result bit and counts itself
                 const uint32_t k = (bounce >> RING_TESTS_SHIFT) & 15u;
                 Q.h_bounce[r] = test ? ((bounce | (T.target == 1 ? 1u << (RING_RESULT_SHIFT + k) : 0u)) + (1u << RING_TESTS_SHIFT)) : bounce;
@@ -425,9 +438,11 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 Q.ro[r] = cam_pos.x, Q.ro[RING_CAP + r] = cam_pos.y, Q.ro[2 * RING_CAP + r] = cam_pos.z;
                 Q.rd[r] = cd.x, Q.rd[RING_CAP + r] = cd.y, Q.rd[2 * RING_CAP + r] = cd.z;
                 Q.r_pid[r] = id, Q.r_bounce[r] = 0u, Q.r_klo[r] = uint32_t(key), Q.r_khi[r] = uint32_t(key >> 32);
+                Q.r_slot[r] = Q.free_slot[free_count - 1u - uint32_t(lane)];
                 if (SQ)
                     Q.r_light[r] = -1;
             }
+            free_count -= cnt;
             next += cnt;
             rq_count += cnt;
         }
@@ -442,7 +457,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 const uint32_t r = (rq_head + rk) % RING_CAP;
                 o = {Q.ro[r], Q.ro[RING_CAP + r], Q.ro[2 * RING_CAP + r]};
                 d = {Q.rd[r], Q.rd[RING_CAP + r], Q.rd[2 * RING_CAP + r]};
-                pid = Q.r_pid[r], bounce = Q.r_bounce[r], klo = Q.r_klo[r], khi = Q.r_khi[r];
+                pid = Q.r_pid[r], bounce = Q.r_bounce[r], klo = Q.r_klo[r], khi = Q.r_khi[r], slot = Q.r_slot[r];
                 const int test_light = SQ ? Q.r_light[r] : -1;
                 if (SQ && test_light >= 0)
                 {

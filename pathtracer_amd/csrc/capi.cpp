@@ -523,6 +523,7 @@ static void from_stats(const ptx::RenderStats &st, ptx_stats *stats)
     stats->ms_total = st.ms_total;
     stats->ms_trace = st.ms_class[0], stats->ms_accumulate = st.ms_class[2];
     stats->ms_other = st.ms_class[3];
+    stats->state_bytes = st.state_bytes;
 }
 
 int ptx_render(ptx_context *c, const ptx_render_opts *o, double *rgb_sum, int32_t out_is_device, ptx_stats *stats)
@@ -536,6 +537,8 @@ int ptx_render(ptx_context *c, const ptx_render_opts *o, double *rgb_sum, int32_
         from_stats(st, stats);
     PTX_CATCH
 }
+
+const char *ptx_context_last_kernel(const ptx_context *c) { return (c && c->ctx) ? c->ctx->last_kernel().c_str() : ""; }
 
 int ptx_render_sharded(ptx_context *const *contexts, int32_t n, const ptx_render_opts *o, int32_t scheme, int32_t exchange,
                        double *rgb_sum, ptx_stats *stats)

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <limits>
 #include <stdexcept>
+#include <string>
 
 namespace ptx
 {
@@ -76,17 +77,26 @@ inline unsigned blocks_for(int64_t n) { return static_cast<unsigned>(std::max<in
 
 } // namespace
 
+// what layout_state sizes the state region for
+struct StateNeeds
+{
+    int64_t paths = 0;     // paths per batch
+    int depth = 1;
+    int waves = 0;         // waves of the tracer's grid
+    int slots = LANE_SLOTS; // record slots per wave
+    size_t ring_bytes = 0; // per wave (ring tracer)
+    int spill_levels = 0;  // traversal stack levels kept in global memory, per lane
+};
+
+constexpr size_t STATIC_STATE_BYTES = size_t(256) << 20;
+
 // per-precision device tables + per-batch path state
 template <class R> struct Context::Impl
 {
     DeviceBuffer tri_pre, mats, lights, tri_nrm;
     DeviceBuffer bvh; // triangle records of the 4-wide BVH
-    DeviceBuffer spill; // traversal stack levels beyond the LDS ones, [level][lane of the launch]
-    DeviceBuffer rings; // ray and hit rings of the ring tracer, one region per wave of the launch
-    DeviceBuffer state_mem; // one slab carved into the DState arrays
+    DeviceBuffer state_mem; // one slab carved into the arrays of a render call (layout_state)
     DState<R> st;
-    int64_t capacity = 0;
-    int depth_cap = 0;
     bool ready = false;
 
     void build_tables(const Scene &sc, const Bvh &bvh, bool brute, hipStream_t s)
@@ -232,38 +242,41 @@ template <class R> struct Context::Impl
         ready = true;
     }
 
-    // carve the state slab for `n` paths of up to `depth` bounces
-    void ensure_state(int64_t n, int depth)
+    // Everything a render call keeps in device memory besides the scene and the image, carved out
+    // of ONE region (`base`; null: only measure): the record slots of the launch's waves, the
+    // per-path results of a batch, statistics, the path-id pool, and for BVH scenes the rings of the
+    // ring tracer and the traversal stack levels the LDS does not hold.  Returns the bytes needed.
+    size_t layout_state(char *base, const StateNeeds &n, uint32_t **spill)
     {
-        if (n <= capacity && depth <= depth_cap)
-            return;
-        n = std::max(n, capacity);
-        depth = std::max(depth, depth_cap);
-        const size_t N = static_cast<size_t>(n);
-        auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
         size_t total = 0;
         auto take = [&](size_t bytes) {
-            size_t off = total;
-            total += align(bytes);
-            return off;
+            const size_t off = total;
+            total += (bytes + 255) & ~size_t(255);
+            return base ? base + off : nullptr;
         };
-        const size_t o_stack = take(N * 6 * sizeof(R) * depth);
-        const size_t o_res = take(N * 3 * sizeof(R));
-        const size_t o_ws = take(static_cast<size_t>(MAX_TRACE_WAVES) * WAVE_STATS * sizeof(unsigned long long));
-        const size_t o_stats = take(sizeof(unsigned long long) * 8);
-        const size_t o_pool = take(sizeof(unsigned int));
-        state_mem.alloc(total);
-        char *base = static_cast<char *>(state_mem.p);
-        st.stack = reinterpret_cast<R *>(base + o_stack);
-        st.result = reinterpret_cast<R *>(base + o_res);
-        st.wave_stats = reinterpret_cast<unsigned long long *>(base + o_ws);
-        st.stats = reinterpret_cast<unsigned long long *>(base + o_stats);
-        st.pool = reinterpret_cast<unsigned int *>(base + o_pool);
-        st.rings = nullptr;
-        st.N = n;
+        const size_t N = static_cast<size_t>(n.paths);
+        st.records = reinterpret_cast<R *>(take(static_cast<size_t>(n.waves) * n.slots * n.depth * REC_STRIDE * sizeof(R)));
+        st.result = reinterpret_cast<R *>(take(N * 3 * sizeof(R)));
+        st.wave_stats = reinterpret_cast<unsigned long long *>(take(static_cast<size_t>(n.waves) * WAVE_STATS * sizeof(unsigned long long)));
+        st.stats = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * 8));
+        st.pool = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int)));
+        st.rings = n.ring_bytes ? take(static_cast<size_t>(n.waves) * n.ring_bytes) : nullptr;
+        *spill = n.spill_levels > 0 ? reinterpret_cast<uint32_t *>(take(static_cast<size_t>(n.waves) * 64 * n.spill_levels * sizeof(uint32_t))) : nullptr;
+        st.N = n.paths;
         st.n_waves = 0;
-        capacity = n;
-        depth_cap = depth;
+        st.slots = n.slots;
+        return total;
+    }
+
+    // grows the slab to `bytes`; the old one is only let go once the new one exists
+    void reserve_state(size_t bytes)
+    {
+        if (bytes <= state_mem.bytes)
+            return;
+        DeviceBuffer bigger;
+        bigger.alloc(bytes);
+        std::swap(bigger.p, state_mem.p);
+        std::swap(bigger.bytes, state_mem.bytes);
     }
 };
 
@@ -358,6 +371,11 @@ Context::Context(int device) : device_(device)
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, device));
     n_cus_ = std::max(prop.multiProcessorCount, 1);
+    // what a render call needs besides device memory is created here, not in the call: two events
+    // and a pinned landing place for the statistics
+    HIP_CHECK(hipEventCreate(&ev_begin_));
+    HIP_CHECK(hipEventCreate(&ev_end_));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&host_stats_), sizeof(unsigned long long) * 8, hipHostMallocDefault));
     f64_ = new Impl<double>();
     f32_ = new Impl<float>();
 }
@@ -368,6 +386,12 @@ Context::~Context()
     delete f64_;
     delete f32_;
     delete geo_;
+    if (ev_begin_)
+        (void)hipEventDestroy(ev_begin_);
+    if (ev_end_)
+        (void)hipEventDestroy(ev_end_);
+    if (host_stats_)
+        (void)hipHostFree(host_stats_);
 }
 
 void Context::set_stream(void *s) { stream_ = s; }
@@ -616,6 +640,7 @@ void Context::vistest(const double *p1, const double *p2, int64_t n, int32_t *vi
 template <class R> struct TracePlan
 {
     void (*kernel)(DScene<R>, DCamera, DBatch, DState<R>, int) = nullptr;
+    std::string name; // which instantiation, as profilers print it (k_trace_f64<true, true, 1>, ...)
     int blocks_per_cu = 1;
     size_t dyn_lds = 0; // bytes of traversal stacks per workgroup (BVH kernels)
     int stack_levels = 0; // levels of them
@@ -650,6 +675,11 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
         pick(std::true_type());
     else
         pick(std::false_type());
+    {
+        char nm[96];
+        std::snprintf(nm, sizeof(nm), "k_trace_%s<%s, %s, %d>", sizeof(R) == 8 ? "f64" : "f32", BRUTE ? "true" : "false", tab ? "true" : "false", lights);
+        p.name = nm;
+    }
     if (!BRUTE && S.n_square <= 12 && rings)
     {
         // the tracer that keeps more paths in flight than lanes (its state word counts up to 12
@@ -662,6 +692,9 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
         else
             p.kernel = tab ? (sq ? k_trace_rings_f32<true, true> : k_trace_rings_f32<true, false>)
                            : (sq ? k_trace_rings_f32<false, true> : k_trace_rings_f32<false, false>);
+        char nm[96];
+        std::snprintf(nm, sizeof(nm), "k_trace_rings_%s<%s, %s>", sizeof(R) == 8 ? "f64" : "f32", tab ? "true" : "false", sq ? "true" : "false");
+        p.name = nm;
     }
     // BVH kernels: how many stack levels to keep in LDS.  The registers (and the static LDS)
     // allow `by_regs` workgroups per CU; the stacks get what is left of the CU's LDS at that
@@ -720,13 +753,13 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
     return p;
 }
 
+// grid_blocks: the persistent grid the state region was laid out for; a batch with fewer paths
+// than that grid has lanes starts fewer workgroups
 template <class R>
 static void launch_trace(const TracePlan<R> &plan, const DScene<R> &S, const DCamera &cam, const DBatch &B, DState<R> &st, hipStream_t s,
-                         int chunk, int n_cus)
+                         int chunk, int grid_blocks)
 {
-    int64_t blocks = static_cast<int64_t>(plan.blocks_per_cu) * n_cus;
-    blocks = std::min<int64_t>(blocks, MAX_TRACE_WAVES / (BLOCK / 64));
-    blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (B.n_paths + BLOCK - 1) / BLOCK));
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(grid_blocks, (B.n_paths + BLOCK - 1) / BLOCK));
     st.n_waves = static_cast<int>(blocks) * (BLOCK / 64);
     hipLaunchKernelGGL(plan.kernel, dim3(static_cast<unsigned>(blocks)), dim3(BLOCK), plan.dyn_lds, s, S, cam, B, st, chunk);
     HIP_CHECK(hipGetLastError());
@@ -785,7 +818,7 @@ RenderTimers::~RenderTimers()
         (void)hipEventDestroy(e);
 }
 
-template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, double *d_sum, RenderStats &stats)
+template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, double *d_sum, RenderStats &stats, bool static_state)
 {
     hipStream_t s = static_cast<hipStream_t>(stream_);
     const Scene &sc = scene_;
@@ -820,53 +853,77 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
         return;
     const int n_cols = c1 - c0;
 
-    int64_t batch = o.batch_paths > 0 ? o.batch_paths : default_batch_paths;
-    batch = std::max<int64_t>(batch, n_cols);
-    const int rows_per_chunk = static_cast<int>(std::min<int64_t>(n_local_rows, std::max<int64_t>(1, batch / n_cols)));
-    const int64_t pix_per_chunk = static_cast<int64_t>(rows_per_chunk) * n_cols;
-    const int samples_per_batch = static_cast<int>(std::min<int64_t>(spp, std::max<int64_t>(1, batch / pix_per_chunk)));
-    const int64_t cap = pix_per_chunk * samples_per_batch;
-    if (cap >= (int64_t(1) << 31))
-        throw std::runtime_error("arg: batch_paths must stay below 2^31");
-    const int chunk = std::max(64, chunk_paths);
-    im.ensure_state(cap, depth);
-    HIP_CHECK(hipMemsetAsync(im.st.stats, 0, sizeof(unsigned long long) * 8, s));
-    HIP_CHECK(hipMemsetAsync(im.st.pool, 0, sizeof(unsigned int), s));
-
     auto S = make_dscene<R>(sc, *geo_, im.tri_pre.p, im.mats.p, im.lights.p, im.tri_nrm.p, im.bvh.p, brute_);
     DCamera cam = make_camera(sc);
-    RenderTimers *tm = o.profile ? &timers_ : nullptr;
+    RenderTimers *tm = (o.profile && !static_state) ? &timers_ : nullptr;
     // The grid of the tracer is just large enough to fill the device: its waves are persistent.
     const TracePlan<R> plan = brute_ ? plan_trace<R, true>(S, trace_blocks_per_cu, shadow_queue, 0, 0)
                                     : plan_trace<R, false>(S, trace_blocks_per_cu, shadow_queue, geo_->stack_need, lds_stack_levels, bvh_rings);
-    if (plan.rings)
+    last_kernel_ = plan.name;
+
+    // ---- size the batch and the grid so that the state fits the memory there is --------------
+    // The record slots belong to the waves of the grid (a path holds one from its start to its
+    // resolve pass), so the state does not grow with the batch except for 3 scalars per path.
+    int64_t batch = o.batch_paths > 0 ? o.batch_paths : default_batch_paths;
+    batch = std::max<int64_t>(batch, n_cols);
+    int grid_blocks = static_cast<int>(std::min<int64_t>(static_cast<int64_t>(plan.blocks_per_cu) * n_cus_, MAX_TRACE_WAVES / (BLOCK / 64)));
+    size_t budget = STATIC_STATE_BYTES;
+    if (!static_state)
     {
-        const int64_t waves = std::min<int64_t>(static_cast<int64_t>(plan.blocks_per_cu) * n_cus_, MAX_TRACE_WAVES / (BLOCK / 64)) * (BLOCK / 64);
-        const size_t bytes = static_cast<size_t>(waves) * ring_bytes<R>();
-        if (im.rings.bytes < bytes)
-            im.rings.alloc(bytes);
-        im.st.rings = static_cast<char *>(im.rings.p);
+        size_t free_b = 0, total_b = 0;
+        HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        budget = static_cast<size_t>(0.9 * static_cast<double>(free_b + im.state_mem.bytes));
     }
+    StateNeeds need;
+    int rows_per_chunk = 1, samples_per_batch = 1;
+    int64_t cap = 0;
+    uint32_t *spill = nullptr;
+    for (;;)
+    {
+        rows_per_chunk = static_cast<int>(std::min<int64_t>(n_local_rows, std::max<int64_t>(1, batch / n_cols)));
+        const int64_t pix_per_chunk = static_cast<int64_t>(rows_per_chunk) * n_cols;
+        samples_per_batch = static_cast<int>(std::min<int64_t>(spp, std::max<int64_t>(1, batch / pix_per_chunk)));
+        cap = pix_per_chunk * samples_per_batch;
+        if (cap >= (int64_t(1) << 31))
+            throw std::runtime_error("arg: batch_paths must stay below 2^31");
+        need.paths = cap, need.depth = depth;
+        need.waves = grid_blocks * (BLOCK / 64);
+        need.slots = plan.rings ? RING_SLOTS : LANE_SLOTS;
+        need.ring_bytes = plan.rings ? ring_bytes<R>() : 0;
+        need.spill_levels = brute_ ? 0 : std::max(geo_->stack_need - plan.stack_levels, 0);
+        if (im.layout_state(nullptr, need, &spill) <= budget)
+            break;
+        // too large: first smaller batches (they cost a few per cent at most), then a smaller grid
+        if (batch > std::max<int64_t>(n_cols, int64_t(1) << 18))
+            batch = std::max<int64_t>(std::max<int64_t>(n_cols, int64_t(1) << 18), batch / 2);
+        else if (grid_blocks > 8)
+            grid_blocks = grid_blocks * 3 / 4;
+        else
+            throw std::runtime_error(static_state
+                                         ? "arg: this depth and image width do not fit the static state region of ptx_render_static (256 MiB); use ptx_render"
+                                         : "device: not enough device memory for the path state at this depth");
+    }
+    char *base;
+    if (static_state)
+        base = reinterpret_cast<char *>(static_state_); // the device address of the region, never the symbol's name
+    else
+    {
+        im.reserve_state(im.layout_state(nullptr, need, &spill));
+        base = static_cast<char *>(im.state_mem.p);
+    }
+    im.layout_state(base, need, &spill);
     if (!brute_)
     {
         // stack levels the LDS does not hold: one column per lane of the launch in global memory
         S.stack_levels = plan.stack_levels;
-        const int over = geo_->stack_need - plan.stack_levels;
-        if (over > 0)
-        {
-            const int64_t lanes = std::min<int64_t>(static_cast<int64_t>(plan.blocks_per_cu) * n_cus_, MAX_TRACE_WAVES / (BLOCK / 64)) * BLOCK;
-            const size_t bytes = static_cast<size_t>(lanes) * over * sizeof(uint32_t);
-            if (im.spill.bytes < bytes)
-                im.spill.alloc(bytes);
-            S.spill = static_cast<uint32_t *>(im.spill.p);
-            S.spill_stride = static_cast<int>(lanes);
-        }
+        S.spill = spill;
+        S.spill_stride = need.waves * 64;
     }
+    const int chunk = std::max(64, chunk_paths);
+    HIP_CHECK(hipMemsetAsync(im.st.stats, 0, sizeof(unsigned long long) * 8, s));
+    HIP_CHECK(hipMemsetAsync(im.st.pool, 0, sizeof(unsigned int), s));
 
-    hipEvent_t ev0, ev1;
-    HIP_CHECK(hipEventCreate(&ev0));
-    HIP_CHECK(hipEventCreate(&ev1));
-    HIP_CHECK(hipEventRecord(ev0, s));
+    HIP_CHECK(hipEventRecord(ev_begin_, s));
     uint64_t passes = 0;
     for (int lr0 = 0; lr0 < n_local_rows; lr0 += rows_per_chunk)
     {
@@ -886,19 +943,17 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
             B.n_paths = B.n_pix * B.n_samples;
             if (tm)
                 tm->mark(s, RenderTimers::TRACE);
-            launch_trace<R>(plan, S, cam, B, im.st, s, chunk, n_cus_);
+            launch_trace<R>(plan, S, cam, B, im.st, s, chunk, grid_blocks);
             launch_finish<R>(S, B, im.st, d_sum, s, tm);
             passes++;
         }
     }
-    HIP_CHECK(hipEventRecord(ev1, s));
-    unsigned long long h_stats[8] = {0};
-    HIP_CHECK(hipMemcpyAsync(h_stats, im.st.stats, sizeof(h_stats), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipEventRecord(ev_end_, s));
+    HIP_CHECK(hipMemcpyAsync(host_stats_, im.st.stats, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, s)); // pinned: a plain DMA
     HIP_CHECK(hipStreamSynchronize(s));
     float ms = 0;
-    HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
+    HIP_CHECK(hipEventElapsedTime(&ms, ev_begin_, ev_end_));
+    const unsigned long long *h_stats = host_stats_;
     stats.segments = h_stats[0];
     stats.shadow_rays = h_stats[1];
     stats.paths = h_stats[2];
@@ -908,17 +963,20 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     stats.bvh_tris = h_stats[6];
     stats.passes = passes;
     stats.ms_total = ms;
+    stats.state_bytes = im.layout_state(nullptr, need, &spill);
     if (tm)
         tm->collect(stats.ms_class);
 }
 
-void Context::render(const RenderOpts &o, double *sum, bool out_is_device, RenderStats &stats)
+void Context::render(const RenderOpts &o, double *sum, bool out_is_device, RenderStats &stats, bool static_state)
 {
     require_scene();
     HIP_CHECK(hipSetDevice(device_));
     hipStream_t s = static_cast<hipStream_t>(stream_);
     stats = RenderStats();
     const int64_t n = static_cast<int64_t>(scene_.width) * scene_.height;
+    if (static_state)
+        throw std::runtime_error("arg: no static state region in this build");
     DeviceBuffer tmp;
     double *d_sum = sum;
     if (!out_is_device)
@@ -933,9 +991,9 @@ void Context::render(const RenderOpts &o, double *sum, bool out_is_device, Rende
     if (scene_.enable_path_tracing)
     {
         if (o.mode == PTX_MODE_F64_)
-            render_impl(*f64_, o, d_sum, stats);
+            render_impl(*f64_, o, d_sum, stats, static_state);
         else if (o.mode == PTX_MODE_F32_)
-            render_impl(*f32_, o, d_sum, stats);
+            render_impl(*f32_, o, d_sum, stats, static_state);
         else
             throw std::runtime_error("arg: unknown render mode");
     }

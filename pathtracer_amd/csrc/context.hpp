@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <string>
 #include <vector>
 
 namespace ptx
@@ -31,6 +32,7 @@ struct RenderStats
     uint64_t paths = 0, segments = 0, shadow_rays = 0, passes = 0, wave_iterations = 0, records = 0, bvh_nodes = 0, bvh_tris = 0;
     double ms_total = 0;
     double ms_class[4] = {0, 0, 0, 0}; // trace, (unused), accumulate, other
+    uint64_t state_bytes = 0;          // device memory of the call's path state (records, results, rings, ...)
 };
 
 // per-kernel-class timing with HIP events on the render stream (profiling mode only)
@@ -65,7 +67,11 @@ public:
     void generate_rays(double *rays_o, double *rays_d);
     void raycast(const double *ro, const double *rd, int64_t n, int32_t *ids, double *pts, bool from_camera, int mode);
     void vistest(const double *p1, const double *p2, int64_t n, int32_t *vis);
-    void render(const RenderOpts &o, double *sum, bool out_is_device, RenderStats &stats);
+    // static_state: the path state lives in the library's static device region instead of
+    // allocated memory, and the call allocates nothing (ptx_render_static)
+    void render(const RenderOpts &o, double *sum, bool out_is_device, RenderStats &stats, bool static_state = false);
+    // name of the tracer kernel the last render launched, as profilers print it
+    const std::string &last_kernel() const { return last_kernel_; }
 
     const Bvh &bvh() const { return bvh_; }
     bool brute_force() const { return brute_; }
@@ -78,7 +84,7 @@ public:
 
     // scenes up to this many triangles are intersected by the all-triangles loop
     int brute_force_limit = 64;
-    int64_t default_batch_paths = int64_t(1) << 26;
+    int64_t default_batch_paths = int64_t(1) << 25;
     // path ids a wave of the tracer takes from the pool at a time (>= 64)
     int chunk_paths = 64;
     // workgroups of the tracer per compute unit (<= 0: what the occupancy calculator reports)
@@ -97,7 +103,7 @@ public:
 
 private:
     void require_scene() const;
-    template <class R> void render_impl(Impl<R> &im, const RenderOpts &o, double *d_sum, RenderStats &stats);
+    template <class R> void render_impl(Impl<R> &im, const RenderOpts &o, double *d_sum, RenderStats &stats, bool static_state);
 
     int device_;
     int n_cus_ = 1;
@@ -110,6 +116,10 @@ private:
     Impl<double> *f64_ = nullptr;
     Impl<float> *f32_ = nullptr;
     RenderTimers timers_;
+    unsigned char *static_state_ = nullptr;     // device address of this GPU's copy of the static state region
+    hipEvent_t ev_begin_ = nullptr, ev_end_ = nullptr;
+    unsigned long long *host_stats_ = nullptr;  // pinned
+    std::string last_kernel_;
 };
 
 // One frame over n contexts (one per GPU, one host thread each) and the final reduce of the sums

@@ -86,10 +86,17 @@ __device__ __forceinline__ int local_row_to_image_row(const DBatch &b, int lr)
     return b.region_row0 + (bi * b.row_stride + b.row_phase) * b.band + off;
 }
 
+// scalars of one record slot: direct rgb, coefficient rgb, two unused -- 64 bytes in f64 (32 in
+// f32), aligned, so that a record is one memory sector however the slots are handed out
+constexpr int REC_STRIDE = 8;
+constexpr int LANE_SLOTS = 192; // record slots of a wave of the lane tracers: 64 paths on the lanes + at most 127 awaiting their resolve pass
+constexpr int RING_SLOTS = 320; // of the ring tracer: at most 192 paths in flight + 127 awaiting their resolve pass
+
 // per-batch device state.  pid = sample_local * n_pix + pixel_local numbers the paths of a batch.
 template <class R> struct DState
 {
-    R *stack;                       // [N][depth][6] by pid: direct rgb, coefficient rgb of every bounce
+    R *records;                     // [n_waves][slots][depth][REC_STRIDE]: the (direct, coefficient) records of the paths a wave
+                                    // has in flight; a path holds one slot from its start to its resolve pass
     R *result;                      // [3][N] by pid: resolved per-sample radiance (written by the tracer)
     unsigned long long *wave_stats; // [n_waves][WAVE_STATS] segments, shadow tests, wave iterations, records, BVH node visits, BVH triangle visits
     unsigned long long *stats;      // [8] totals (filled by k_reduce_stats)
@@ -97,7 +104,14 @@ template <class R> struct DState
     char *rings;                    // [n_waves][ring_bytes<R>()] ray and hit rings of the ring tracer (BVH scenes)
     int64_t N;                      // capacity (paths per batch)
     int n_waves;                    // waves of the current batch
+    int slots;                      // record slots per wave (LANE_SLOTS or RING_SLOTS)
 };
+
+// the record of (wave g, slot, bounce)
+template <class R> __device__ __forceinline__ R *record_at(const DState<R> &st, int g, uint32_t slot, int depth, uint32_t bounce)
+{
+    return st.records + ((size_t(g) * size_t(st.slots) + slot) * size_t(depth) + bounce) * REC_STRIDE;
+}
 
 // ---------------------------------------------------------------------------------------------
 // intersectors
@@ -712,8 +726,8 @@ struct __attribute__((packed, aligned(4))) Float9
 };
 __device__ __forceinline__ Float9 load9(const float *p) { return *reinterpret_cast<const Float9 *>(p); }
 
-// one (direct rgb, coefficient rgb) record of a path's stack: 16-byte aligned in f64 (three 16-byte
-// loads), 8-byte aligned in f32 (three 8-byte loads)
+// one (direct rgb, coefficient rgb) record of a path: 64-byte aligned in f64 (three 16-byte loads),
+// 32-byte aligned in f32 (a 16-byte and an 8-byte load)
 __device__ __forceinline__ void load_record(const double *rec, double *q)
 {
     const uint4 *r = reinterpret_cast<const uint4 *>(rec);
@@ -724,9 +738,20 @@ __device__ __forceinline__ void load_record(const double *rec, double *q)
 }
 __device__ __forceinline__ void load_record(const float *rec, float *q)
 {
-    const float2 *r = reinterpret_cast<const float2 *>(rec);
-    const float2 a = r[0], b = r[1], c = r[2];
-    q[0] = a.x, q[1] = a.y, q[2] = b.x, q[3] = b.y, q[4] = c.x, q[5] = c.y;
+    const float4 a = *reinterpret_cast<const float4 *>(rec);
+    const float2 b = *reinterpret_cast<const float2 *>(rec + 4);
+    q[0] = a.x, q[1] = a.y, q[2] = a.z, q[3] = a.w, q[4] = b.x, q[5] = b.y;
+}
+// the store side: 48 (24) bytes in 3 (2) stores
+__device__ __forceinline__ void store_record(double *rec, V3<double> direct, V3<double> coef)
+{
+    double2 *r = reinterpret_cast<double2 *>(rec);
+    r[0] = double2{direct.x, direct.y}, r[1] = double2{direct.z, coef.x}, r[2] = double2{coef.y, coef.z};
+}
+__device__ __forceinline__ void store_record(float *rec, V3<float> direct, V3<float> coef)
+{
+    *reinterpret_cast<float4 *>(rec) = float4{direct.x, direct.y, direct.z, coef.x};
+    *reinterpret_cast<float2 *>(rec + 4) = float2{coef.y, coef.z};
 }
 
 __device__ __forceinline__ int global_wave() { return int((blockIdx.x * BLOCK + threadIdx.x) >> 6); }
@@ -763,19 +788,21 @@ template <class R> struct ShadowQueue
     R xi[2][CAP];                   // the two draws the light sample point is a function of
     R p2[3][CAP];                   // shaded point
     uint32_t own_bounce[CAP];       // (triangle the shaded point lies on << 16) | bounce
-    uint32_t pid[CAP];              // own_bounce, pid: which bounce record the result belongs to
+    uint8_t slot[CAP];              // own_bounce, slot: which bounce record the result belongs to
 };
 struct NoQueue
 {
 };
 
 // Finished paths of one wave waiting for their resolve pass (ring buffer in LDS): path id,
-// (record count << 16) | (tail material + 1), and how many visibility tests the wave had parked
-// when the path ended -- once that many have been tested, no test of this path is pending.
+// (record count << 16) | (tail material + 1), the record slot, and how many visibility tests the
+// wave had parked when the path ended (a wrapping 16-bit count: the queues are far shorter) --
+// once that many have been tested, no test of this path is pending.
 struct DoneQueue
 {
     static constexpr int CAP = 128;
-    uint32_t pid[CAP], state[CAP], need[CAP];
+    uint32_t pid[CAP], state[CAP];
+    uint16_t need[CAP], slot[CAP];
 };
 
 // LIGHTS selects how visibility tests are compiled: 0 -- the scene has no square light, there are
@@ -802,6 +829,9 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
     __shared__ RayBlock<R> ray_blocks[BLOCK / 64];
     __shared__ typename std::conditional<SQ1, ShadowQueue<R>, NoQueue>::type shadow_queues[BLOCK / 64];
     __shared__ DoneQueue done_queues[BLOCK / 64];
+    __shared__ uint8_t free_slots[BLOCK / 64][LANE_SLOTS]; // per wave: the record slots no path holds (a stack)
+    for (int k = threadIdx.x; k < (BLOCK / 64) * LANE_SLOTS; k += BLOCK)
+        free_slots[k / LANE_SLOTS][k % LANE_SLOTS] = uint8_t(k % LANE_SLOTS);
     if (TAB)
     {
         for (int k = threadIdx.x; k < S.n_mats * MAT_STRIDE; k += BLOCK)
@@ -837,6 +867,9 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
     uint32_t sq_pushed = 0, sq_drained = 0; // running totals (wave-uniform, wrap around)
     DoneQueue &dq = done_queues[threadIdx.x >> 6];
     uint32_t dq_head = 0, dq_count = 0; // wave-uniform
+    uint8_t *free_slot = free_slots[threadIdx.x >> 6];
+    uint32_t free_count = LANE_SLOTS;   // wave-uniform; never runs out: 64 paths on the lanes + at most 127 in dq
+    uint32_t slot = 0;                  // the record slot of this lane's path
 
     bool alive = false;
     bool trav_done = false; // BVH: the lane's closest-hit traversal is complete (its path waits for shading)
@@ -884,7 +917,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 if (!visible<R, BRUTE>(S, a, b, stk, int(ob >> 16), blockers))
                 {
                     // same wave, later in program order than the store of the term: this one wins
-                    R *rec = st.stack + ((size_t)sq.pid[e] * depth + (ob & 0xffffu)) * 6;
+                    R *rec = record_at(st, g, sq.slot[e], depth, ob & 0xffffu);
                     rec[0] = R(0), rec[1] = R(0), rec[2] = R(0);
                 }
             }
@@ -903,7 +936,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         if constexpr (SQ1)
         {
             const uint32_t need_n = uint32_t(__builtin_amdgcn_readfirstlane(int(dq.need[(dq_head + n - 1u) % DoneQueue::CAP])));
-            while (int32_t(sq_drained - need_n) < 0)
+            while (int16_t(uint16_t(sq_drained) - uint16_t(need_n)) < 0)
                 drain(sq_count < 64u ? sq_count : 64u);
         }
         // the records were stored by other lanes of this same wave: waiting for those stores is
@@ -914,6 +947,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         const uint32_t e = (dq_head + uint32_t(lane)) % DoneQueue::CAP;
         const bool mine = uint32_t(lane) < n;
         const uint32_t rp = mine ? dq.pid[e] : 0u, rs = mine ? dq.state[e] : 0u;
+        const uint32_t rslot = mine ? uint32_t(dq.slot[e]) : 0u;
         const int len = int(rs >> 16), tm = int(rs & 0xffffu);
         R fr = R(0), fg = R(0), fb = R(0);
         if (tm)
@@ -928,7 +962,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         int wlen = len; // longest stack of the wave: the loop below has a wave-uniform trip count
         for (int off = 32; off > 0; off >>= 1)
             wlen = max(wlen, __shfl_xor(wlen, off, 64));
-        const R *rec = st.stack + (size_t)rp * depth * 6;
+        const R *rec = record_at(st, g, rslot, depth, 0u);
         // four levels per trip: their loads are issued together, so the wave waits for the memory
         // system once per four bounces instead of once per bounce
         constexpr int G = 4;
@@ -942,7 +976,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 const bool on = i >= 0 && i < len;
                 q[k][0] = q[k][1] = q[k][2] = q[k][3] = q[k][4] = q[k][5] = R(0);
                 if (on) // lanes whose stack is shorter do not touch memory
-                    load_record(rec + i * 6, q[k]); // 48 (24) bytes in 3 loads
+                    load_record(rec + i * REC_STRIDE, q[k]); // 48 (24) bytes in 3 (2) loads
             }
 #pragma unroll
             for (int k = 0; k < G; k++)
@@ -971,9 +1005,17 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             }
         }
         if (mine)
+        {
             st.result[rp] = fr, st.result[st.N + rp] = fg, st.result[2 * st.N + rp] = fb;
+            free_slot[free_count + uint32_t(lane)] = uint8_t(rslot); // the slots go back on the stack
+        }
+        free_count += n;
         dq_head = (dq_head + n) % DoneQueue::CAP;
         dq_count -= n;
+        // the next path to start reads the stack the lanes above just wrote
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
     for (;;)
@@ -1037,6 +1079,14 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        {
+            // the lanes that start a path now each take a record slot off the wave's stack
+            const bool starts = !alive && blk_pos + uint32_t(__popcll(idle & lt_mask)) < blk_cnt;
+            const unsigned long long sm = __ballot(starts);
+            if (starts)
+                slot = free_slot[free_count - 1u - uint32_t(__popcll(sm & lt_mask))];
+            free_count -= uint32_t(__popcll(sm));
+        }
         if (!alive)
         {
             const uint32_t e = blk_pos + uint32_t(__popcll(idle & lt_mask));
@@ -1093,7 +1143,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
 
         bool park = false; // this lane has a visibility test for the queue
         R park_x1 = R(0), park_x2 = R(0);
-        const uint32_t seg_pid = pid, seg_bounce = uint32_t(bounce);
+        const uint32_t seg_pid = pid, seg_bounce = uint32_t(bounce), seg_slot = slot;
         if (shaded)
         {
             // ---- shading normal: precomputed per triangle when it is flat (its three vertex normals
@@ -1172,9 +1222,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             }
 
             // ---- one stack record per shaded segment -------------------------------------------------
-            R *rec = st.stack + ((size_t)pid * depth + bounce) * 6;
-            rec[0] = direct.x, rec[1] = direct.y, rec[2] = direct.z;
-            rec[3] = coef.x, rec[4] = coef.y, rec[5] = coef.z;
+            store_record(record_at(st, g, slot, depth, uint32_t(bounce)), direct, coef);
             n_rec++;
             if (S.enable_indirect && bounce + 1 < depth)
             {
@@ -1198,7 +1246,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 sq.xi[0][e] = park_x1, sq.xi[1][e] = park_x2;
                 sq.p2[0][e] = p.x, sq.p2[1][e] = p.y, sq.p2[2][e] = p.z;
                 sq.own_bounce[e] = (uint32_t(hit_k) << 16) | seg_bounce;
-                sq.pid[e] = seg_pid;
+                sq.slot[e] = uint8_t(seg_slot);
             }
             sq_count += uint32_t(__popcll(pm));
             sq_pushed += uint32_t(__popcll(pm));
@@ -1211,14 +1259,14 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             if (finished)
             {
                 const uint32_t e = (dq_head + dq_count + uint32_t(__popcll(fm & lt_mask))) % DoneQueue::CAP;
-                dq.pid[e] = seg_pid, dq.state[e] = fin_state, dq.need[e] = sq_pushed;
+                dq.pid[e] = seg_pid, dq.state[e] = fin_state, dq.need[e] = uint16_t(sq_pushed), dq.slot[e] = uint16_t(seg_slot);
             }
             dq_count += uint32_t(__popcll(fm));
             if (dq_count >= 64u)
             {
                 // resolve once the 64th path in line has no parked test left (or the ring fills up)
                 const uint32_t need64 = uint32_t(__builtin_amdgcn_readfirstlane(int(dq.need[(dq_head + 63u) % DoneQueue::CAP])));
-                if (int32_t(sq_drained - need64) >= 0 || dq_count > uint32_t(DoneQueue::CAP) - 64u)
+                if (int16_t(uint16_t(sq_drained) - uint16_t(need64)) >= 0 || dq_count > uint32_t(DoneQueue::CAP) - 64u)
                     resolve(64u);
             }
         }

@@ -133,33 +133,49 @@ int fix_index(int idx, int n)
     return -1;
 }
 
-// 4x4 inverse through 2x2 sub-determinants (row-major)
+// 4x4 inverse (row-major): adjugate by cofactor expansion -- every cofactor the sum of six signed
+// triple products, taken left to right -- divided by the determinant along row 0.  The CPU
+// restatement the parity tests compare with uses the same expansion, term by term: camera rays are
+// compared bit for bit, and the raster -> world matrix is where they start.
 void invert4(const double *m, double *inv)
 {
-    double s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2];
-    double s2 = m[0] * m[7] - m[4] * m[3], s3 = m[1] * m[6] - m[5] * m[2];
-    double s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
-    double c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11];
-    double c3 = m[9] * m[14] - m[13] * m[10], c2 = m[8] * m[15] - m[12] * m[11];
-    double c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
-    double det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    double a[16];
+    a[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] +
+           m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    a[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] -
+           m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    a[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] +
+           m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    a[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] -
+            m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    a[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] -
+           m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    a[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] +
+           m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    a[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] -
+           m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    a[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] +
+            m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    a[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] +
+           m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    a[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] -
+           m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    a[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] +
+            m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    a[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] -
+            m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    a[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] -
+           m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    a[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] +
+           m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    a[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] -
+            m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    a[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] +
+            m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    double det = m[0] * a[0] + m[1] * a[4] + m[2] * a[8] + m[3] * a[12];
     double id = 1.0 / det;
-    inv[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * id;
-    inv[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * id;
-    inv[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * id;
-    inv[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * id;
-    inv[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * id;
-    inv[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * id;
-    inv[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * id;
-    inv[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * id;
-    inv[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * id;
-    inv[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * id;
-    inv[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * id;
-    inv[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * id;
-    inv[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * id;
-    inv[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * id;
-    inv[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * id;
-    inv[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * id;
+    for (int i = 0; i < 16; i++)
+        inv[i] = a[i] * id;
 }
 
 void mul4(const double *a, const double *b, double *o)

@@ -40,8 +40,9 @@ def assert_f64_parity(img, oimg, st=None, ost=None, depth=15, ctx=None, O=None, 
     OUTLIERS.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], n_bad, int(diff.size)))
     if n_bad:
         assert ctx is not None and O is not None, "%d of %d pixels differ by more than %g" % (n_bad, diff.size, F64_TOL)
-        assert n_bad <= max(2, diff.size // 500), "%d of %d pixels differ: too many to be ties" % (n_bad, diff.size)
         n_spp = int(spp if spp is not None else O.c.spp)
+        # a guard against proving thousands of pixels one by one (about 1 path in 2000 meets a tie in the Cornell box)
+        assert n_bad <= max(2, diff.size * n_spp // 500), "%d of %d pixels differ: too many to be ties" % (n_bad, diff.size)
         for r, c in bad:
             y, x = int(r) + origin[0], int(c) + origin[1]
             explained = 0.0
@@ -137,6 +138,32 @@ def test_raycast_and_vistest_operators_bit_exact(cbox64):
     vis = c.vistest(p1, p2)
     ovis = np.array([O.vistest(a, b) for a, b in zip(p1, p2)])
     assert np.array_equal(vis, ovis) and 0.05 < vis.mean() < 0.98
+
+
+@pytest.mark.parametrize("conf", ["config/cbox.conf", "config/mis.conf"])
+def test_raycast_takes_directions_of_any_length(root, conf):
+    """cAccelStruct::RayCast does not normalise the direction (tRay::Init keeps it as given): hits,
+    points and ties are those of the unit ray whatever |d| is -- on the all-triangles intersector
+    (Cornell box) and through the BVH (mis), whose culling bounds are distances."""
+    s, ref = load(root, conf, width=32, height=32, spp=1)
+    c, O = make_ctx(s), oracle.Oracle(ref, seed=13)
+    lo, hi = ref.verts.reshape(-1, 3).min(0), ref.verts.reshape(-1, 3).max(0)
+    rng = np.random.default_rng(7)
+    n = 6000
+    o = rng.uniform(lo, hi, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    unit_ids, unit_pts = c.raycast(o, d)
+    assert (unit_ids >= 0).mean() > 0.3
+    for scale in (1e-3, 0.1, 10.0, 1e4):
+        ids, pts = c.raycast(o, d * scale)
+        for i in range(0, n, 5):
+            f, p = O.closest_hit(o[i], d[i] * scale)
+            assert f == ids[i] and np.array_equal(p, pts[i], equal_nan=True), (scale, i)
+        # the same faces as at unit length, except where two candidates are a few ulps apart
+        assert (ids != unit_ids).mean() < 1e-3
+    ids, _ = c.raycast(o[:64], np.zeros((64, 3)))                       # no direction: no hit (NaN everywhere)
+    assert (ids == -1).all()
 
 
 def test_bvh_traversal_equals_brute_force(root):
