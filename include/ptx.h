@@ -180,6 +180,19 @@ int ptx_vistest(ptx_context *, const double *p1, const double *p2, int64_t n, in
  * counter profiles to the kernel that actually ran. */
 const char *ptx_context_last_kernel(const ptx_context *);
 
+/* ptx_render_static: ptx_render for callers that cannot allocate -- code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.
+ * Same kernels, same results as ptx_render with out_is_device != 0 (rgb_sum is DEVICE memory,
+ * [H*W][3] double, on the context's GPU), but the path state (record slots, per-path results,
+ * statistics, rings, stack spill) lives in a region of 256 MiB that the library holds in every
+ * GPU's memory from load to unload, and the call makes no hipMalloc / hipFree or other allocating
+ * call (events and the pinned landing place of the statistics belong to the context).  Batches
+ * and the tracer's grid are cut down to what fits the region, so large frames take more launches
+ * than under ptx_render; a depth and image width whose smallest state does not fit is rejected with
+ * PTX_ERR_ARG.  opts->profile is ignored.  All contexts of one GPU share that GPU's region and it
+ * keeps the last call's contents: the call clears what must start at zero, and calls that overlap
+ * on one GPU (two host threads, two streams) race -- serialise them. */
+int ptx_render_static(ptx_context *, const ptx_render_opts *, double *rgb_sum_device, ptx_stats *stats);
 
 /* ---- one frame over several GPUs of one node ---------------------------------------------------
  * ptx_render_sharded shards the row loop of cPathTracer::RayTracing (src/tracing/cPathTracer.cpp:

@@ -69,6 +69,7 @@ SYMBOLS = {
     "ptx_generate_rays": (C.c_int, [_VP, _VP, _VP]),
     "ptx_first_hit": (C.c_int, [_VP, _VP, _VP]),
     "ptx_render": (C.c_int, [_VP, C.POINTER(RenderOpts), _VP, C.c_int32, C.POINTER(Stats)]),
+    "ptx_render_static": (C.c_int, [_VP, C.POINTER(RenderOpts), _VP, C.POINTER(Stats)]),
     "ptx_context_last_kernel": (C.c_char_p, [_VP]),
     "ptx_render_sharded": (C.c_int, [_VP, C.c_int32, C.POINTER(RenderOpts), C.c_int32, C.c_int32, _VP, _VP]),
     "ptx_raycast": (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP]),

@@ -235,6 +235,17 @@ class Context:
         return _stats_dict(st)
 
 
+    def render_static(self, device_ptr, mode="f64", spp=None, sample_offset=0, spp_total=None,
+                      rows=None, row_stride=1, row_phase=0, band=1, depth=None, seed=13,
+                      batch_paths=None, accumulate=False):
+        """render_device through ptx_render_static: the path state lives in the library's static
+        device region and the call allocates nothing."""
+        o = self._opts(mode, spp, sample_offset, spp_total, rows, row_stride, row_phase, band,
+                       depth, seed, batch_paths, accumulate, False)
+        st = _lib.Stats()
+        check(_lib.lib().ptx_render_static(self._h, C.byref(o), C.c_void_p(int(device_ptr)), C.byref(st)))
+        return _stats_dict(st)
+
     def last_kernel(self):
         return _lib.lib().ptx_context_last_kernel(self._h).decode()
 

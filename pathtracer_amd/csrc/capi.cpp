@@ -538,6 +538,18 @@ int ptx_render(ptx_context *c, const ptx_render_opts *o, double *rgb_sum, int32_
     PTX_CATCH
 }
 
+int ptx_render_static(ptx_context *c, const ptx_render_opts *o, double *rgb_sum_device, ptx_stats *stats)
+{
+    if (!c || !c->ctx || !rgb_sum_device)
+        return fail_arg("ptx_render_static: null argument");
+    PTX_TRY
+    ptx::RenderStats st;
+    c->ctx->render(to_opts(o), rgb_sum_device, true, st, /*static_state=*/true);
+    if (stats)
+        from_stats(st, stats);
+    PTX_CATCH
+}
+
 const char *ptx_context_last_kernel(const ptx_context *c) { return (c && c->ctx) ? c->ctx->last_kernel().c_str() : ""; }
 
 int ptx_render_sharded(ptx_context *const *contexts, int32_t n, const ptx_render_opts *o, int32_t scheme, int32_t exchange,

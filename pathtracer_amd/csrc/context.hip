@@ -88,7 +88,12 @@ struct StateNeeds
     int spill_levels = 0;  // traversal stack levels kept in global memory, per lane
 };
 
+// State region of ptx_render_static: device memory the library owns from load to unload, one
+// copy per GPU, so that a render call through that entry point allocates nothing.  Host code must
+// not use the array's name as an address (it is a host-side stand-in): the device address comes
+// from hipGetSymbolAddress, once per device, in Context::Context.
 constexpr size_t STATIC_STATE_BYTES = size_t(256) << 20;
+static __device__ __align__(256) unsigned char scratch[STATIC_STATE_BYTES];
 
 // per-precision device tables + per-batch path state
 template <class R> struct Context::Impl
@@ -371,6 +376,8 @@ Context::Context(int device) : device_(device)
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, device));
     n_cus_ = std::max(prop.multiProcessorCount, 1);
+    // this device's copy of the static state region (every GPU has its own, at its own address)
+    HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void **>(&static_state_), HIP_SYMBOL(scratch)));
     // what a render call needs besides device memory is created here, not in the call: two events
     // and a pinned landing place for the statistics
     HIP_CHECK(hipEventCreate(&ev_begin_));
@@ -975,8 +982,8 @@ void Context::render(const RenderOpts &o, double *sum, bool out_is_device, Rende
     hipStream_t s = static_cast<hipStream_t>(stream_);
     stats = RenderStats();
     const int64_t n = static_cast<int64_t>(scene_.width) * scene_.height;
-    if (static_state)
-        throw std::runtime_error("arg: no static state region in this build");
+    if (static_state && !out_is_device)
+        throw std::runtime_error("arg: ptx_render_static writes to device memory only");
     DeviceBuffer tmp;
     double *d_sum = sum;
     if (!out_is_device)

@@ -1,0 +1,75 @@
+"""ptx_render_static -- the entry point that allocates nothing -- through the C ABI, against
+ptx_render on the same inputs: bit for bit, on calls in a row that reuse the library's static state
+region with different layouts (a large frame on the all-triangles intersector, then a smaller
+frame of a BVH scene through the ring tracer, then a few rows of the first again)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import pathtracer_amd as pt
+from test_gpu_parity import load, make_ctx
+
+pytestmark = pytest.mark.gpu
+
+
+def both(c, shape, **kw):
+    a = torch.full(shape, -1.0, dtype=torch.float64, device="cuda")
+    b = torch.full(shape, -2.0, dtype=torch.float64, device="cuda")
+    st_a = c.render_static(a.data_ptr(), **kw)
+    st_b = c.render_device(b.data_ptr(), **kw)
+    torch.cuda.synchronize()
+    return a.cpu().numpy(), b.cpu().numpy(), st_a, st_b
+
+
+def test_static_state_render_equals_allocating_render(root):
+    s1, _ = load(root, "config/cbox.conf", width=320, height=256, spp=8)
+    s2, _ = load(root, "config/mis.conf", width=96, height=64, spp=3)
+    c1, c2 = make_ctx(s1), make_ctx(s2)
+    assert c1.accel_info()["brute_force"] and not c2.accel_info()["brute_force"]
+    for mode in ("f64", "f32"):
+        a, b, sa, sb = both(c1, (256, 320, 3), mode=mode)                      # first call: the larger input
+        assert np.array_equal(a, b) and a.max() > 0
+        assert all(sa[k] == sb[k] for k in ("paths", "segments", "shadow_rays", "records"))
+        assert 0 < sa["state_bytes"] <= 256 << 20
+        a, b, sa, sb = both(c2, (64, 96, 3), mode=mode)                        # second call: a smaller one, another layout
+        assert np.array_equal(a, b) and a.max() > 0
+        assert all(sa[k] == sb[k] for k in ("paths", "segments", "shadow_rays", "records", "bvh_nodes", "bvh_tris"))
+        a, b, sa, sb = both(c1, (256, 320, 3), mode=mode, rows=(100, 108), spp=2)
+        assert np.array_equal(a, b) and sa["paths"] == 8 * 320 * 2
+    # nothing is allocated: the device's free memory is the same before and after a call
+    out = torch.zeros((256, 320, 3), dtype=torch.float64, device="cuda")
+    c1.render_static(out.data_ptr(), mode="f64")
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    c1.render_static(out.data_ptr(), mode="f64", spp=3)
+    c2_out = torch.zeros((64, 96, 3), dtype=torch.float64, device="cuda")
+    free0 = torch.cuda.mem_get_info()[0]
+    c2.render_static(c2_out.data_ptr(), mode="f64")
+    c1.render_static(out.data_ptr(), mode="f32")
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    # accumulate continues the sums already in the buffer, as ptx_render does
+    full, _ = c1.render(mode="f64")
+    c1.render_static(out.data_ptr(), mode="f64", spp=4, sample_offset=0, spp_total=8)
+    c1.render_static(out.data_ptr(), mode="f64", spp=4, sample_offset=4, spp_total=8, accumulate=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), full)
+
+
+def test_static_state_render_rejects_what_does_not_fit(root):
+    s, _ = load(root, "config/cbox.conf", width=1024, height=64, spp=1)
+    c = make_ctx(s)
+    out = torch.zeros((64, 1024, 3), dtype=torch.float64, device="cuda")
+    with pytest.raises(pt.PtxError) as e:
+        c.render_static(out.data_ptr(), mode="f64", depth=60000)               # 192 slots x 60000 bounces x 64 B per wave
+    assert e.value.code == 1 and "static state region" in e.value.message
+    st = c.render_static(out.data_ptr(), mode="f64", depth=200)                # a deep path still fits on a smaller grid
+    ref = torch.zeros_like(out)
+    st2 = c.render_device(ref.data_ptr(), mode="f64", depth=200)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and st["segments"] == st2["segments"]
+    with pytest.raises(pt.PtxError):
+        _lib_null = pt.lib().ptx_render_static(c._h, None, None, None)
+        pt._lib.check(_lib_null)
