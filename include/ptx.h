@@ -28,6 +28,19 @@ extern "C" {
 #define PTX_MODE_F64 0 /* reference arithmetic: double everywhere, no FMA contraction           */
 #define PTX_MODE_F32 1 /* fast path: float state and tests, statistically equivalent images     */
 
+/* Which estimator ptx_render runs.  REFERENCE is cPathTracer::RayTracePrimaryRay as written
+ * (src/tracing/cPathTracer.cpp:555-704: every light sampled without a weight, the reference's
+ * direction sampler, unshadowed sphere lights, the per-bounce clamp) -- what parity is defined
+ * against.  FAST has no counterpart in the reference: the same scene description rendered by a
+ * physically based forward path tracer -- light sampling weighted against BRDF sampling by the
+ * balance heuristic, cosine / Phong-lobe importance sampling, Russian roulette from bounce 3 on,
+ * sphere lights sampled on their cone WITH a visibility test, no per-bounce clamp.  The conf
+ * lights emit but do not occlude (sampled directions that cross one collect it); faces of an
+ * emissive material end a path and count when the camera sees them, directly or through glass.
+ * The two estimators converge to different images. */
+#define PTX_ESTIMATOR_REFERENCE 0
+#define PTX_ESTIMATOR_FAST 1
+
 typedef struct ptx_scene ptx_scene;
 typedef struct ptx_context ptx_context;
 
@@ -65,6 +78,7 @@ typedef struct ptx_render_opts
     int64_t batch_paths;   /* paths in flight per pass (<=0: library default)                    */
     int32_t accumulate;    /* != 0: add to the sums already in the output buffer                 */
     int32_t profile;       /* != 0: time every kernel with HIP events (fills ms_*)                 */
+    int32_t estimator;     /* PTX_ESTIMATOR_REFERENCE | PTX_ESTIMATOR_FAST                         */
 } ptx_render_opts;
 
 typedef struct ptx_stats

@@ -27,6 +27,7 @@ class OrcScene(C.Structure):
         ("enable_indirect", C.c_int32), ("enable_bary_normal", C.c_int32),
         ("region", C.c_int32 * 4), ("seed", C.c_uint64),
         ("sample_offset", C.c_int32), ("spp_total", C.c_int32), ("use_bvh", C.c_int32),
+        ("estimator", C.c_int32), ("fast_strategy", C.c_int32),
     ]
 
 
@@ -82,7 +83,9 @@ def _v3(x):
 class Oracle:
     """Holds a scene in the layout pt_oracle.c expects and exposes its entry points."""
 
-    def __init__(self, scene, seed=13, use_bvh=None):
+    def __init__(self, scene, seed=13, use_bvh=None, estimator="reference", fast_strategy=0):
+        """estimator: "reference" (the reference's own, what parity is defined against) or "fast"
+        (the physically based one: MIS, lobe sampling, Russian roulette, shadowed sphere lights)."""
         self.scene = scene
         self._keep = dict(
             verts=np.ascontiguousarray(scene.verts, dtype=np.float64),
@@ -111,6 +114,8 @@ class Oracle:
         if use_bvh is None:
             use_bvh = s.n_tris > 256
         s.use_bvh = int(bool(use_bvh))
+        s.estimator = {"reference": 0, "fast": 1}[estimator]
+        s.fast_strategy = int(fast_strategy)
         self.c = s
         if s.use_bvh:
             lib().orc_bvh_build(C.byref(s))

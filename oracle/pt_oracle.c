@@ -59,6 +59,10 @@ typedef struct
     int32_t sample_offset; /* global index of the first sample rendered (sample-range sharding)   */
     int32_t spp_total;     /* divisor of the per-sample average (== spp when not sharded)         */
     int32_t use_bvh;       /* 0: brute force over all faces (reference accel "None")             */
+    int32_t estimator;     /* 0: the reference's estimator; 1: the physically based one ("fast")  */
+    int32_t fast_strategy; /* fast estimator, for its own tests: 0 both sampling strategies with
+                              the balance heuristic; 1 light sampling alone; 2 BRDF sampling alone
+                              (the three agree in the mean wherever no delta lobe is involved)     */
 } orc_scene;
 
 typedef struct
@@ -608,10 +612,19 @@ static void quat_rot(const double *q, const double *v, double *o)
 }
 
 /* cMathUtil::SampleHemiSphereUniform (cMathUtil.cpp:230-267) with explicit xi inputs */
+/* rotates `res`, a vector given about +Y, onto the frame whose +Y is n: the rotation of
+ * cMathUtil::SampleHemiSphereUniform (cMathUtil.cpp:242-265) */
+static void rot_from_y(const double *n, const double *res, double *out);
+
 void orc_sample_hemisphere(const double *n, double xi1, double xi2, double *out)
 {
     double theta = acos(1 - xi1), phi = 2 * M_PI * xi2;
     double res[3] = {cos(theta) * cos(phi), sin(theta), -cos(theta) * sin(phi)};
+    rot_from_y(n, res, out);
+}
+
+static void rot_from_y(const double *n, const double *res, double *out)
+{
     double y[3] = {0, 1, 0}, nmy[3] = {n[0] - y[0], n[1] - y[1], n[2] - y[2]}, ax0[3], axis[3];
     cross3(y, nmy, ax0);
     normalize3(ax0, axis);
@@ -1041,6 +1054,351 @@ static void trace_sample(const orc_scene *sc, const double *o0, const double *d0
     }
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* The physically based estimator ("fast" mode).  It has NO counterpart in the reference, whose  */
+/* estimator samples every light without a weight, draws pole-peaked "uniform" directions, never */
+/* shadows sphere lights, has no Russian roulette and clamps every bounce (cBxDF.cpp:16-52,      */
+/* cMathUtil.cpp:230-267, cLight.cpp:216, cPathTracer.cpp:589,685-688).  This one is a forward   */
+/* path tracer over the same scene description:                                                  */
+/*  - BRDF  f = Kd/pi + Ks (Ns+2)/(2 pi) max(0, r.wi)^Ns  (the reference's lobe, clamped),       */
+/*    sampled by lobe: cosine hemisphere with probability pd = max Kd / (max Kd + max Ks), else   */
+/*    the Phong lobe about the mirror direction; two-sided (the normal is turned to the viewer); */
+/*  - glass (Ni != 1): Schlick reflect / refract with the material's own Ni, a delta lobe;       */
+/*  - every conf light is sampled at every non-delta bounce (square: uniform area, one-sided;     */
+/*    sphere: uniform cone, or the whole sphere from inside) with a visibility test to the        */
+/*    sampled point -- sphere lights included -- and weighted by the balance heuristic against    */
+/*    the BRDF's density of that direction;                                                       */
+/*  - the conf lights are shapes that emit and do not occlude: a BRDF-sampled ray that crosses    */
+/*    one before its next surface collects Li with the complementary weight (weight 1 after a     */
+/*    delta bounce); camera rays and delta chains from the camera do not see them;                */
+/*  - faces of an emissive material (Ka) end the path; their Ka counts only when the camera sees  */
+/*    them, directly or through delta bounces (they are the visible stand-ins of the lights: the  */
+/*    scene format keeps the two apart, so nothing else can avoid counting the light twice);      */
+/*    (at the last bounce the depth allows, the light sample counts whole);                       */
+/*  - Russian roulette from bounce 3 on: survival q = min(0.95, max throughput);                  */
+/*  - no clamp before the final image.                                                            */
+/* Random numbers: light l dimensions 4l, 4l+1; lobe / Fresnel choice 4 n_lights, direction      */
+/* 4 n_lights + 1, + 2, roulette 4 n_lights + 3.                                                  */
+/* ------------------------------------------------------------------------------------------ */
+static inline double max3(const double *a)
+{
+    double m = a[0] > a[1] ? a[0] : a[1];
+    return m > a[2] ? m : a[2];
+}
+
+/* density (solid angle, seen from o along unit d) with which light L is sampled towards the
+ * point where the ray (o, d) crosses it, and the distance to that point; 0 when the ray misses
+ * the light or meets a square light from behind */
+double orc_fast_light_pdf(const double *L, const double *o, const double *d, double *t_out)
+{
+    *t_out = INFINITY;
+    if (L[0] == 0.0)
+    {
+        const double *P0 = L + 4, *P1 = L + 7, *P2 = L + 10;
+        double N[3], e10[3], e21[3];
+        orc_normal_from_3pts(P0, P1, P2, N);
+        for (int i = 0; i < 3; i++)
+            e10[i] = P1[i] - P0[i], e21[i] = P2[i] - P1[i];
+        double dn = dot3(d, N);
+        if (!(dn < 0))
+            return 0; /* the light emits on the side its normal points to */
+        double g[3] = {P0[0] - o[0], P0[1] - o[1], P0[2] - o[2]};
+        double t = dot3(g, N) / dn;
+        if (!(t > 1e-6))
+            return 0;
+        double h[3] = {o[0] + t * d[0] - P0[0], o[1] + t * d[1] - P0[1], o[2] + t * d[2] - P0[2]};
+        double u = dot3(h, e10) / dot3(e10, e10), v = dot3(h, e21) / dot3(e21, e21);
+        if (u < 0 || u > 1 || v < 0 || v > 1)
+            return 0;
+        *t_out = t;
+        return t * t / (norm3(e21) * norm3(e10) * -dn);
+    }
+    const double *C = L + 4;
+    double R = L[7];
+    double g[3] = {C[0] - o[0], C[1] - o[1], C[2] - o[2]};
+    double dc2 = dot3(g, g), b = dot3(g, d), disc = b * b - dc2 + R * R;
+    if (!(disc >= 0))
+        return 0;
+    double sq = sqrt(disc);
+    if (dc2 > R * R)
+    {
+        double t = b - sq;
+        if (!(t > 1e-6))
+            return 0;
+        *t_out = t;
+        return 1.0 / (2 * M_PI * (1 - sqrt(1 - R * R / dc2)));
+    }
+    *t_out = b + sq;
+    return 1.0 / (4 * M_PI);
+}
+
+/* one light sample from the shaded point p: direction wi (unit, towards the light), the point q
+ * on the light, the density of wi; returns 0 when the sample is of no use */
+double orc_fast_light_sample(const double *L, const double *p, double xi1, double xi2, double *wi, double *q)
+{
+    if (L[0] == 0.0)
+    {
+        const double *P0 = L + 4, *P1 = L + 7, *P2 = L + 10;
+        double N[3], e10[3], e21[3];
+        orc_normal_from_3pts(P0, P1, P2, N);
+        for (int i = 0; i < 3; i++)
+            e10[i] = P1[i] - P0[i], e21[i] = P2[i] - P1[i];
+        for (int i = 0; i < 3; i++)
+        {
+            q[i] = P0[i] + e10[i] * xi1;
+            q[i] += e21[i] * xi2;
+        }
+        double w[3] = {q[0] - p[0], q[1] - p[1], q[2] - p[2]};
+        double d2 = dot3(w, w);
+        if (!(d2 > 0))
+            return 0;
+        double dl = sqrt(d2);
+        for (int i = 0; i < 3; i++)
+            wi[i] = w[i] / dl;
+        double cl = -dot3(wi, N);
+        if (!(cl > 0))
+            return 0;
+        return d2 / (norm3(e21) * norm3(e10) * cl);
+    }
+    const double *C = L + 4;
+    double R = L[7];
+    double g[3] = {C[0] - p[0], C[1] - p[1], C[2] - p[2]};
+    double dc2 = dot3(g, g), dc = sqrt(dc2);
+    if (dc2 > R * R)
+    {
+        double axis[3] = {g[0] / dc, g[1] / dc, g[2] / dc};
+        double s2max = R * R / dc2, cmax = sqrt(1 - s2max);
+        double ct = 1 - xi1 * (1 - cmax), st2 = 1 - ct * ct, st = sqrt(st2 > 0 ? st2 : 0), phi = 2 * M_PI * xi2;
+        double loc[3] = {st * cos(phi), ct, -st * sin(phi)};
+        rot_from_y(axis, loc, wi);
+        double disc = R * R - dc2 * st2;
+        double t = dc * ct - sqrt(disc > 0 ? disc : 0);
+        for (int i = 0; i < 3; i++)
+            q[i] = p[i] + t * wi[i];
+        return 1.0 / (2 * M_PI * (1 - cmax));
+    }
+    /* inside the sphere: any direction reaches it */
+    double ct = 1 - 2 * xi1, st = sqrt(1 - ct * ct > 0 ? 1 - ct * ct : 0), phi = 2 * M_PI * xi2;
+    wi[0] = st * cos(phi), wi[1] = ct, wi[2] = -st * sin(phi);
+    double b = dot3(g, wi), t = b + sqrt(b * b - dc2 + R * R);
+    for (int i = 0; i < 3; i++)
+        q[i] = p[i] + t * wi[i];
+    return 1.0 / (4 * M_PI);
+}
+
+/* BRDF value and sampling density for outward unit directions wi (to the light) and wo (to the
+ * viewer) about the normal n (n.wo >= 0) */
+void orc_fast_brdf(const double *mat, const double *n, const double *wo, const double *wi, double *f, double *pdf)
+{
+    double cn = dot3(n, wi);
+    f[0] = f[1] = f[2] = 0, *pdf = 0;
+    if (!(cn > 0))
+        return;
+    double k = 2 * dot3(n, wo), r[3] = {k * n[0] - wo[0], k * n[1] - wo[1], k * n[2] - wo[2]};
+    double ca = dot3(r, wi), ns = mat[10];
+    double pw = ca > 0 ? pow(ca, ns) : 0;
+    double kd = max3(mat + 3), ks = max3(mat + 6);
+    for (int i = 0; i < 3; i++)
+        f[i] = mat[3 + i] / M_PI + mat[6 + i] * ((ns + 2) / (2 * M_PI)) * pw;
+    if (kd + ks > 0)
+    {
+        double pd = kd / (kd + ks);
+        *pdf = pd * cn / M_PI + (1 - pd) * ((ns + 1) / (2 * M_PI)) * pw;
+    }
+}
+
+/* next direction of a BRDF surface from three draws; returns 0 when the path ends here */
+int orc_fast_brdf_sample(const double *mat, const double *n, const double *wo, const double *xi, double *wi)
+{
+    double kd = max3(mat + 3), ks = max3(mat + 6), ns = mat[10];
+    if (!(kd + ks > 0))
+        return 0;
+    double pd = kd / (kd + ks), phi = 2 * M_PI * xi[2];
+    if (xi[0] < pd)
+    {
+        double r = sqrt(xi[1]), h = sqrt(1 - xi[1]);
+        double loc[3] = {r * cos(phi), h, -r * sin(phi)};
+        rot_from_y(n, loc, wi);
+    }
+    else
+    {
+        double ca = pow(xi[1], 1.0 / (ns + 1)), sa = sqrt(1 - ca * ca > 0 ? 1 - ca * ca : 0);
+        double k = 2 * dot3(n, wo), r[3] = {k * n[0] - wo[0], k * n[1] - wo[1], k * n[2] - wo[2]};
+        double loc[3] = {sa * cos(phi), ca, -sa * sin(phi)};
+        rot_from_y(r, loc, wi);
+    }
+    return dot3(n, wi) > 0;
+}
+
+/* glass: reflect or refract, chosen by Schlick's reflectance against one draw */
+void orc_fast_glass_sample(const double *mat, const double *n_, const double *wo, double xi, double *wi)
+{
+    double ni = mat[9], n[3] = {n_[0], n_[1], n_[2]};
+    double ci = dot3(n, wo), eta = 1.0 / ni;
+    if (ci < 0)
+    {
+        n[0] = -n[0], n[1] = -n[1], n[2] = -n[2];
+        ci = -ci, eta = ni;
+    }
+    double s2t = eta * eta * (1 - ci * ci);
+    double r0 = (1 - ni) / (1 + ni);
+    r0 *= r0;
+    int reflect = 1;
+    double ct = 0;
+    if (s2t < 1)
+    {
+        ct = sqrt(1 - s2t);
+        double c = eta > 1 ? ct : ci, x = 1 - c, x2 = x * x;
+        double Rf = r0 + (1 - r0) * (x2 * x2 * x);
+        reflect = xi < Rf;
+    }
+    for (int i = 0; i < 3; i++)
+        wi[i] = reflect ? 2 * ci * n[i] - wo[i] : (eta * ci - ct) * n[i] - eta * wo[i];
+}
+
+static void fast_sample(const orc_scene *sc, const double *o0, const double *d0, uint32_t pixel, uint32_t sample,
+                        double *Lout, orc_stats *st, orc_probe *probe)
+{
+    int depth = sc->depth > ORC_MAX_DEPTH ? ORC_MAX_DEPTH : sc->depth;
+    double o[3] = {o0[0], o0[1], o0[2]}, d[3] = {d0[0], d0[1], d0[2]};
+    double T[3] = {1, 1, 1}, Lsum[3] = {0, 0, 0};
+    double pdf_prev = 0; /* density of the direction this segment was sampled with; < 0: a delta lobe */
+    int eye_chain = 1;   /* only delta bounces since the camera */
+    const int D0 = 4 * sc->n_lights;
+    if (st)
+        st->paths++;
+    if (probe)
+        probe->n = 0;
+    for (int bounce = 0; bounce < depth; bounce++)
+    {
+        double p[3], second = INFINITY;
+        if (st)
+            st->segments++;
+        int32_t f = closest(sc, o, d, p, st, probe ? &second : NULL);
+        double t_geom = INFINITY;
+        if (f >= 0)
+        {
+            double e[3] = {p[0] - o[0], p[1] - o[1], p[2] - o[2]};
+            t_geom = norm3(e);
+        }
+        if (probe)
+        {
+            probe->face[probe->n] = f;
+            probe->margin[probe->n] = f < 0 ? INFINITY : second - t_geom;
+            probe->n++;
+        }
+        /* conf lights crossed by a sampled direction before the surface: emitters that do not occlude */
+        if (bounce > 0 && !eye_chain)
+            for (int32_t l = 0; l < sc->n_lights; l++)
+            {
+                const double *L = sc->lights + (size_t)l * 16;
+                double tl, pl = orc_fast_light_pdf(L, o, d, &tl);
+                if (pl > 0 && tl < t_geom)
+                {
+                    double w = pdf_prev < 0 ? 1.0 : pdf_prev / (pdf_prev + pl);
+                    if (pdf_prev >= 0 && sc->fast_strategy)
+                        w = sc->fast_strategy == 2 ? 1.0 : 0.0;
+                    for (int k = 0; k < 3; k++)
+                        Lsum[k] += T[k] * L[1 + k] * w;
+                }
+            }
+        int32_t mid;
+        if (f < 0 || (mid = sc->mat_ids[f]) == -1)
+            break;
+        const double *mat_ = sc->mats + (size_t)mid * 12;
+        if (norm3(mat_) > 1e-6)
+        {
+            if (eye_chain)
+                for (int k = 0; k < 3; k++)
+                    Lsum[k] += T[k] * mat_[k];
+            break;
+        }
+        const double *v = sc->verts + (size_t)f * 9;
+        double n[3];
+        if (sc->enable_bary_normal)
+        {
+            double w[3], acc[3] = {0, 0, 0};
+            const double *vn = sc->normals + (size_t)f * 9;
+            orc_barycentric(p, v, v + 3, v + 6, w);
+            for (int i = 0; i < 3; i++)
+                for (int k = 0; k < 3; k++)
+                    acc[k] += w[i] * vn[i * 3 + k];
+            normalize3(acc, n);
+        }
+        else
+            orc_normal_from_3pts(v, v + 3, v + 6, n);
+        double wo[3] = {-d[0], -d[1], -d[2]}, wi[3];
+        if (orc_is_bsdf(mat_))
+        {
+            if (!sc->enable_indirect)
+                break;
+            double xi = orc_rng(sc->seed, pixel, sample, (uint32_t)bounce, D0);
+            orc_fast_glass_sample(mat_, n, wo, xi, wi);
+            pdf_prev = -1;
+        }
+        else
+        {
+            if (dot3(n, wo) < 0)
+                n[0] = -n[0], n[1] = -n[1], n[2] = -n[2];
+            for (int32_t l = 0; l < sc->n_lights; l++)
+            {
+                const double *L = sc->lights + (size_t)l * 16;
+                double x1 = orc_rng(sc->seed, pixel, sample, (uint32_t)bounce, 4 * l + 0);
+                double x2 = orc_rng(sc->seed, pixel, sample, (uint32_t)bounce, 4 * l + 1);
+                double wl[3], q[3], fl[3], pb;
+                double pl = orc_fast_light_sample(L, p, x1, x2, wl, q);
+                if (!(pl > 0))
+                    continue;
+                orc_fast_brdf(mat_, n, wo, wl, fl, &pb);
+                if (!(dot3(n, wl) > 0))
+                    continue;
+                if (st)
+                    st->shadow_rays++;
+                if (!vistest_impl(sc, q, p, st))
+                    continue;
+                /* cos / pl times the balance weight pl / (pl + pb); at the last bounce no sampled
+                 * direction follows that could collect the other share: the light sample counts whole */
+                int last = !sc->enable_indirect || bounce + 1 >= depth;
+                double w = last ? dot3(n, wl) / pl : dot3(n, wl) / (pl + pb);
+                if (sc->fast_strategy && !last)
+                    w = sc->fast_strategy == 1 ? dot3(n, wl) / pl : 0.0;
+                for (int k = 0; k < 3; k++)
+                    Lsum[k] += T[k] * L[1 + k] * fl[k] * w;
+            }
+            if (!sc->enable_indirect)
+                break;
+            double xi[3];
+            for (int k = 0; k < 3; k++)
+                xi[k] = orc_rng(sc->seed, pixel, sample, (uint32_t)bounce, D0 + k);
+            if (!orc_fast_brdf_sample(mat_, n, wo, xi, wi))
+                break;
+            double fb[3], pb;
+            orc_fast_brdf(mat_, n, wo, wi, fb, &pb);
+            if (!(pb > 0))
+                break;
+            double c = dot3(n, wi) / pb;
+            for (int k = 0; k < 3; k++)
+                T[k] *= fb[k] * c;
+            pdf_prev = pb;
+            eye_chain = 0;
+        }
+        if (bounce >= 3)
+        {
+            double q = max3(T);
+            if (q > 0.95)
+                q = 0.95;
+            double xr = orc_rng(sc->seed, pixel, sample, (uint32_t)bounce, D0 + 3);
+            if (!(xr < q))
+                break;
+            for (int k = 0; k < 3; k++)
+                T[k] /= q;
+        }
+        for (int i = 0; i < 3; i++)
+            o[i] = p[i], d[i] = wi[i];
+    }
+    Lout[0] = Lsum[0], Lout[1] = Lsum[1], Lout[2] = Lsum[2];
+}
+
 static void trace_pixel(const orc_scene *sc, const double *mat, int x, int y, double *sum_out,
                         orc_stats *st)
 {
@@ -1051,7 +1409,10 @@ static void trace_pixel(const orc_scene *sc, const double *mat, int x, int y, do
     for (int s = 0; s < sc->spp; s++)
     {
         double final[3];
-        trace_sample(sc, o0, d0, pixel, (uint32_t)(sc->sample_offset + s), final, st, NULL);
+        if (sc->estimator == 1)
+            fast_sample(sc, o0, d0, pixel, (uint32_t)(sc->sample_offset + s), final, st, NULL);
+        else
+            trace_sample(sc, o0, d0, pixel, (uint32_t)(sc->sample_offset + s), final, st, NULL);
         for (int k = 0; k < 3; k++)
             color[k] += final[k] / sc->spp_total;
     }
@@ -1068,7 +1429,10 @@ int32_t orc_trace_sample(const orc_scene *sc, int x, int y, int sample, double *
     orc_probe pr;
     orc_camera_matrix(sc, mat);
     primary_ray(sc, mat, x, y, o0, d0);
-    trace_sample(sc, o0, d0, (uint32_t)(y * sc->width + x), (uint32_t)sample, rgb, NULL, &pr);
+    if (sc->estimator == 1)
+        fast_sample(sc, o0, d0, (uint32_t)(y * sc->width + x), (uint32_t)sample, rgb, NULL, &pr);
+    else
+        trace_sample(sc, o0, d0, (uint32_t)(y * sc->width + x), (uint32_t)sample, rgb, NULL, &pr);
     for (int i = 0; i < pr.n; i++)
     {
         if (faces)

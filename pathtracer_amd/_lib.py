@@ -14,6 +14,8 @@ LIB_PATH = os.environ.get("PTX_LIB_OVERRIDE") or os.path.join(_HERE, "libptx_amd
 PTX_OK = 0
 PTX_MODE_F64 = 0
 PTX_MODE_F32 = 1
+PTX_ESTIMATOR_REFERENCE = 0
+PTX_ESTIMATOR_FAST = 1
 
 
 class Overrides(C.Structure):
@@ -35,7 +37,7 @@ class RenderOpts(C.Structure):
                 ("spp_total", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32),
                 ("row_stride", C.c_int32), ("row_phase", C.c_int32), ("band", C.c_int32),
                 ("depth", C.c_int32), ("seed", C.c_uint64), ("batch_paths", C.c_int64),
-                ("accumulate", C.c_int32), ("profile", C.c_int32)]
+                ("accumulate", C.c_int32), ("profile", C.c_int32), ("estimator", C.c_int32)]
 
 
 class Stats(C.Structure):

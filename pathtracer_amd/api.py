@@ -197,7 +197,7 @@ class Context:
         return vis.astype(bool)
 
     def _opts(self, mode, spp, sample_offset, spp_total, rows, row_stride, row_phase, band, depth,
-              seed, batch_paths, accumulate, profile):
+              seed, batch_paths, accumulate, profile, estimator="reference"):
         o = _lib.RenderOpts()
         o.mode = _MODES[mode]
         o.spp, o.sample_offset, o.spp_total = int(spp or 0), int(sample_offset), int(spp_total or 0)
@@ -209,27 +209,29 @@ class Context:
         o.batch_paths = int(batch_paths or 0)
         o.accumulate = int(bool(accumulate))
         o.profile = int(bool(profile))
+        o.estimator = {"reference": 0, "fast": 1, 0: 0, 1: 1}[estimator]
         return o
 
     def render(self, mode="f64", spp=None, sample_offset=0, spp_total=None, rows=None,
                row_stride=1, row_phase=0, band=1, depth=None, seed=13, batch_paths=None,
-               accumulate=False, profile=False, out=None):
-        """Renders into a host array [H,W,3] float64 of pre-final-clamp sums; returns (sum, stats)."""
+               accumulate=False, profile=False, out=None, estimator="reference"):
+        """Renders into a host array [H,W,3] float64 of pre-final-clamp sums; returns (sum, stats).
+        estimator: "reference" (the reference's own) or "fast" (the physically based one)."""
         if out is None:
             out = np.zeros((self.height, self.width, 3))
         o = self._opts(mode, spp, sample_offset, spp_total, rows, row_stride, row_phase, band,
-                       depth, seed, batch_paths, accumulate, profile)
+                       depth, seed, batch_paths, accumulate, profile, estimator)
         st = _lib.Stats()
         check(_lib.lib().ptx_render(self._h, C.byref(o), _ptr(out), 0, C.byref(st)))
         return out, _stats_dict(st)
 
     def render_device(self, device_ptr, mode="f64", spp=None, sample_offset=0, spp_total=None,
                       rows=None, row_stride=1, row_phase=0, band=1, depth=None, seed=13,
-                      batch_paths=None, accumulate=False, profile=False):
+                      batch_paths=None, accumulate=False, profile=False, estimator="reference"):
         """Same, into device memory (H*W*3 doubles) owned by the caller, e.g. a torch tensor's
         data_ptr(); nothing is copied to the host."""
         o = self._opts(mode, spp, sample_offset, spp_total, rows, row_stride, row_phase, band,
-                       depth, seed, batch_paths, accumulate, profile)
+                       depth, seed, batch_paths, accumulate, profile, estimator)
         st = _lib.Stats()
         check(_lib.lib().ptx_render(self._h, C.byref(o), C.c_void_p(int(device_ptr)), 1, C.byref(st)))
         return _stats_dict(st)
@@ -237,11 +239,11 @@ class Context:
 
     def render_static(self, device_ptr, mode="f64", spp=None, sample_offset=0, spp_total=None,
                       rows=None, row_stride=1, row_phase=0, band=1, depth=None, seed=13,
-                      batch_paths=None, accumulate=False):
+                      batch_paths=None, accumulate=False, estimator="reference"):
         """render_device through ptx_render_static: the path state lives in the library's static
         device region and the call allocates nothing."""
         o = self._opts(mode, spp, sample_offset, spp_total, rows, row_stride, row_phase, band,
-                       depth, seed, batch_paths, accumulate, False)
+                       depth, seed, batch_paths, accumulate, False, estimator)
         st = _lib.Stats()
         check(_lib.lib().ptx_render_static(self._h, C.byref(o), C.c_void_p(int(device_ptr)), C.byref(st)))
         return _stats_dict(st)

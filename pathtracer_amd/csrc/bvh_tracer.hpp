@@ -36,35 +36,40 @@ constexpr int RING_TESTS_SHIFT = 16, RING_RESULT_SHIFT = 20, RING_MAX_TESTS = 12
 constexpr int RING_BATCH = 40;      // lanes that hand over hits / take rays together (a hand-over drains the
                                     // wave's outstanding loads; measured plateau: 32 to 48)
 
-// bytes of one wave's two rings and of its stack of free record slots
-template <class R> constexpr size_t ring_bytes() { return size_t(RING_CAP) * (12 * sizeof(R) + 4 * 13) + size_t(RING_SLOTS) * 4; }
+// bytes of one wave's two rings and of its per-slot path table
+template <class R> constexpr size_t ring_bytes() { return size_t(RING_CAP) * (12 * sizeof(R) + 4 * 7) + size_t(RING_SLOTS) * 12; }
+// Record slots of a wave are handed out a generation (64 slots, one per lane) at a time, to the 64
+// camera rays that enter together; a generation is free again once all its paths are resolved.
+constexpr int RING_GENS = RING_SLOTS / 64;
 
-// views of the two rings of one wave (structure of arrays: one field of 256 entries after the other)
+// views of the two rings of one wave (structure of arrays: one field of 256 entries after the
+// other) and of its path table.  What a path is -- its id and the key of its random numbers --
+// stays in the table, indexed by the record slot the path holds; ring entries and lanes carry the
+// slot and the state word only (registers are what the traversal loop is short of).
 template <class R> struct Rings
 {
     // ray ring
     R *ro, *rd;        // [3][CAP] each
-    uint32_t *r_pid, *r_bounce, *r_klo, *r_khi; // r_bounce: state word
+    uint32_t *r_slot, *r_bounce; // r_bounce: state word
     int32_t *r_tri;    // shadow entries: the triangle the shaded point lies on
     int32_t *r_light;  // -1: a ray; else a visibility test (shadow entry) against this light
     // hit ring
     R *hp, *hd;        // [3][CAP]: hit point, ray direction
     int32_t *h_tri;
-    uint32_t *h_pid, *h_bounce, *h_klo, *h_khi; // h_bounce: state word
-    uint32_t *r_slot, *h_slot; // the record slot the entry's path holds
-    uint32_t *free_slot;       // [RING_SLOTS] stack of the record slots no path holds
+    uint32_t *h_slot, *h_bounce; // h_bounce: state word
+    // path table, by record slot
+    uint32_t *s_pid, *s_klo, *s_khi;
     __device__ explicit Rings(void *base)
     {
         R *f = reinterpret_cast<R *>(base);
         ro = f, rd = f + 3 * RING_CAP, hp = f + 6 * RING_CAP, hd = f + 9 * RING_CAP;
         uint32_t *u = reinterpret_cast<uint32_t *>(f + 12 * RING_CAP);
-        r_pid = u, r_bounce = u + RING_CAP, r_klo = u + 2 * RING_CAP, r_khi = u + 3 * RING_CAP;
+        r_slot = u, r_bounce = u + RING_CAP;
+        r_tri = reinterpret_cast<int32_t *>(u + 2 * RING_CAP);
+        r_light = reinterpret_cast<int32_t *>(u + 3 * RING_CAP);
         h_tri = reinterpret_cast<int32_t *>(u + 4 * RING_CAP);
-        h_pid = u + 5 * RING_CAP, h_bounce = u + 6 * RING_CAP, h_klo = u + 7 * RING_CAP, h_khi = u + 8 * RING_CAP;
-        r_tri = reinterpret_cast<int32_t *>(u + 9 * RING_CAP);
-        r_light = reinterpret_cast<int32_t *>(u + 10 * RING_CAP);
-        r_slot = u + 11 * RING_CAP, h_slot = u + 12 * RING_CAP;
-        free_slot = u + 13 * RING_CAP;
+        h_slot = u + 5 * RING_CAP, h_bounce = u + 6 * RING_CAP;
+        s_pid = u + 7 * RING_CAP, s_klo = s_pid + RING_SLOTS, s_khi = s_klo + RING_SLOTS;
     }
 };
 
@@ -111,19 +116,19 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     DoneQueue &dq = done_queues[threadIdx.x >> 6];
     uint32_t dq_head = 0, dq_count = 0;               // wave-uniform
     uint32_t rq_head = 0, rq_count = 0, hq_head = 0, hq_count = 0; // wave-uniform
-    // record slots: a path takes one when its camera ray is admitted and returns it in its resolve
-    // pass; at most 192 paths are in flight and at most 127 wait in dq, so the stack never runs dry
-    for (int k = lane; k < RING_SLOTS; k += 64)
-        Q.free_slot[k] = uint32_t(k);
-    uint32_t free_count = RING_SLOTS; // wave-uniform
-    uint32_t slot = 0;                // of the path whose ray this lane traverses
+    // record slots: paths not yet resolved per generation (wave-uniform: scalar registers)
+    uint32_t gen_live[RING_GENS];
+#pragma unroll
+    for (int k = 0; k < RING_GENS; k++)
+        gen_live[k] = 0u;
+    uint32_t slot = 0; // of the path whose ray this lane traverses
 
     // the ray this lane is traversing
     bool busy = false, done = false; // done: traversal complete, the hit waits to be handed over
     Trav<R> T;
     trav_init(T, V3<R>{R(0), R(0), R(0)}, V3<R>{R(1), R(1), R(1)});
     V3<R> o = {R(0), R(0), R(0)}, d = {R(0), R(0), R(0)};
-    uint32_t pid = 0, bounce = 0, klo = 0, khi = 0;
+    uint32_t bounce = 0; // state word of the ray this lane traverses
     // a visibility test in flight: the hit it belongs to (handed back when the test is done)
     V3<R> vp = {R(0), R(0), R(0)}, vd = {R(0), R(0), R(0)};
     int vtri = -1;
@@ -191,13 +196,21 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             }
         }
         if (mine)
-        {
             st.result[rp] = fr, st.result[st.N + rp] = fg, st.result[2 * st.N + rp] = fb;
-            Q.free_slot[free_count + uint32_t(lane)] = rslot; // the slots go back on the stack
-        }
-        free_count += n;
+#pragma unroll
+        for (int k = 0; k < RING_GENS; k++)
+            gen_live[k] -= uint32_t(__popcll(__ballot(mine && int(rslot >> 6) == k)));
         dq_head = (dq_head + n) % DoneQueue::CAP;
         dq_count -= n;
+    };
+
+    // a generation of record slots no path holds (-1: none)
+    auto free_gen = [&]() {
+        int gen = -1;
+#pragma unroll
+        for (int k = RING_GENS - 1; k >= 0; k--)
+            gen = gen_live[k] == 0u ? k : gen;
+        return gen;
     };
 
     // shades the first n (<= 64) hits of the hit ring, one per lane
@@ -218,7 +231,8 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             p = {Q.hp[e], Q.hp[RING_CAP + e], Q.hp[2 * RING_CAP + e]};
             const V3<R> sd = {Q.hd[e], Q.hd[RING_CAP + e], Q.hd[2 * RING_CAP + e]};
             const int hit_k = Q.h_tri[e];
-            s_pid = Q.h_pid[e], s_bounce = Q.h_bounce[e], s_klo = Q.h_klo[e], s_khi = Q.h_khi[e], s_slot = Q.h_slot[e];
+            s_slot = Q.h_slot[e], s_bounce = Q.h_bounce[e];
+            s_pid = Q.s_pid[s_slot], s_klo = Q.s_klo[s_slot], s_khi = Q.s_khi[s_slot];
             const uint32_t state = s_bounce;
             const int tested = int((state >> RING_TESTS_SHIFT) & 15u); // visibility tests of this bounce already done
             s_bounce &= RING_BOUNCE;
@@ -337,8 +351,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 const V3<R> od = defer ? keep_d : wi;
                 Q.ro[r] = p.x, Q.ro[RING_CAP + r] = p.y, Q.ro[2 * RING_CAP + r] = p.z;
                 Q.rd[r] = od.x, Q.rd[RING_CAP + r] = od.y, Q.rd[2 * RING_CAP + r] = od.z;
-                Q.r_pid[r] = s_pid, Q.r_bounce[r] = defer ? defer_state : s_bounce + 1u;
-                Q.r_klo[r] = s_klo, Q.r_khi[r] = s_khi, Q.r_slot[r] = s_slot;
+                Q.r_slot[r] = s_slot, Q.r_bounce[r] = defer ? defer_state : s_bounce + 1u;
                 if (SQ)
                     Q.r_tri[r] = keep_tri, Q.r_light[r] = defer ? defer_light : -1;
             }
@@ -396,7 +409,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 Q.hp[r] = p.x, Q.hp[RING_CAP + r] = p.y, Q.hp[2 * RING_CAP + r] = p.z;
                 Q.hd[r] = hd.x, Q.hd[RING_CAP + r] = hd.y, Q.hd[2 * RING_CAP + r] = hd.z;
                 Q.h_tri[r] = test ? vtri : T.target;
-                Q.h_pid[r] = pid, Q.h_klo[r] = klo, Q.h_khi[r] = khi, Q.h_slot[r] = slot;
+                Q.h_slot[r] = slot;
                 // a test adds its result bit and counts itself
                 const uint32_t k = (bounce >> RING_TESTS_SHIFT) & 15u;
                 Q.h_bounce[r] = test ? ((bounce | (T.target == 1 ? 1u << (RING_RESULT_SHIFT + k) : 0u)) + (1u << RING_TESTS_SHIFT)) : bounce;
@@ -406,12 +419,17 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             n_busy -= __popcll(gm);
         }
         // ---- 64 hits wait: shade them (fewer only when nothing else is left to do) -----------------
+        // (or when no generation of record slots is free and only shading can finish paths)
         if (hq_count >= 64u)
             shade(64u);
-        else if (hq_count > 0u && n_busy == 0 && rq_count == 0u && drained)
+        else if (hq_count > 0u && n_busy == 0 && rq_count == 0u && (drained || free_gen() < 0))
             shade(hq_count);
         // ---- camera rays enter through the ray ring, 64 at a time ----------------------------------
-        if (!drained && rq_count < 64u && rq_count + hq_count + uint32_t(n_busy) <= uint32_t(RING_ADMIT))
+        const int gen = free_gen();
+        const bool admit = !drained && rq_count < 64u && rq_count + hq_count + uint32_t(n_busy) <= uint32_t(RING_ADMIT);
+        if (admit && gen < 0 && dq_count > 0u)
+            resolve(dq_count < 64u ? dq_count : 64u); // every generation has a path left: finish what waits (rare)
+        if (admit && gen >= 0)
         {
             if (next == end)
             {
@@ -437,12 +455,15 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 const uint32_t r = (rq_head + rq_count + uint32_t(lane)) % RING_CAP;
                 Q.ro[r] = cam_pos.x, Q.ro[RING_CAP + r] = cam_pos.y, Q.ro[2 * RING_CAP + r] = cam_pos.z;
                 Q.rd[r] = cd.x, Q.rd[RING_CAP + r] = cd.y, Q.rd[2 * RING_CAP + r] = cd.z;
-                Q.r_pid[r] = id, Q.r_bounce[r] = 0u, Q.r_klo[r] = uint32_t(key), Q.r_khi[r] = uint32_t(key >> 32);
-                Q.r_slot[r] = Q.free_slot[free_count - 1u - uint32_t(lane)];
+                const uint32_t sl = uint32_t(gen) * 64u + uint32_t(lane);
+                Q.r_slot[r] = sl, Q.r_bounce[r] = 0u;
+                Q.s_pid[sl] = id, Q.s_klo[sl] = uint32_t(key), Q.s_khi[sl] = uint32_t(key >> 32);
                 if (SQ)
                     Q.r_light[r] = -1;
             }
-            free_count -= cnt;
+#pragma unroll
+            for (int k = 0; k < RING_GENS; k++)
+                gen_live[k] += k == gen ? cnt : 0u;
             next += cnt;
             rq_count += cnt;
         }
@@ -457,7 +478,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 const uint32_t r = (rq_head + rk) % RING_CAP;
                 o = {Q.ro[r], Q.ro[RING_CAP + r], Q.ro[2 * RING_CAP + r]};
                 d = {Q.rd[r], Q.rd[RING_CAP + r], Q.rd[2 * RING_CAP + r]};
-                pid = Q.r_pid[r], bounce = Q.r_bounce[r], klo = Q.r_klo[r], khi = Q.r_khi[r], slot = Q.r_slot[r];
+                bounce = Q.r_bounce[r], slot = Q.r_slot[r];
                 const int test_light = SQ ? Q.r_light[r] : -1;
                 if (SQ && test_light >= 0)
                 {
@@ -470,8 +491,8 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                         L = lds_lights + test_light * LIGHT_STRIDE;
                     else
                         L = S.lights + (size_t)test_light * LIGHT_STRIDE;
-                    const uint64_t key = (uint64_t(khi) << 32) | klo;
-                    const uint32_t sample = uint32_t(B.sample0) + pid / n_pix;
+                    const uint64_t key = (uint64_t(Q.s_khi[slot]) << 32) | Q.s_klo[slot];
+                    const uint32_t sample = uint32_t(B.sample0) + Q.s_pid[slot] / n_pix;
                     const R x1 = rng_draw<R>(key, sample, bounce & RING_BOUNCE, 4 * test_light + 0);
                     const R x2 = rng_draw<R>(key, sample, bounce & RING_BOUNCE, 4 * test_light + 1);
                     const V3<R> s = square_light_point(L, x1, x2);

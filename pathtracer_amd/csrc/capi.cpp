@@ -509,6 +509,7 @@ static ptx::RenderOpts to_opts(const ptx_render_opts *o)
         ro.batch_paths = o->batch_paths;
         ro.accumulate = o->accumulate != 0;
         ro.profile = o->profile != 0;
+        ro.estimator = o->estimator;
     }
     return ro;
 }

@@ -655,15 +655,37 @@ template <class R> struct TracePlan
 };
 
 template <class R, bool BRUTE>
-static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shadow_queue, int stack_need, int lds_stack_cap, bool rings = false)
+static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shadow_queue, int stack_need, int lds_stack_cap, bool rings = false,
+                               bool fast = false)
 {
     TracePlan<R> p;
     const bool tab = S.n_mats <= LDS_MATS && S.n_lights <= LDS_LIGHTS;
-    // how visibility tests are compiled (see trace_body): none / parked in the LDS queue / in place
-    const int lights = S.n_square == 0 ? 0 : ((BRUTE && S.n_lights == 1 && shadow_queue) ? 1 : 2);
+    // how visibility tests are compiled (see trace_body): none / parked in the LDS queue / in place.
+    // The reference's estimator tests square lights only, the physically based one every light.
+    const int n_tested = fast ? S.n_lights : S.n_square;
+    const int lights = n_tested == 0 ? 0 : ((BRUTE && S.n_lights == 1 && shadow_queue) ? 1 : 2);
+    if (fast)
+        rings = false; // the physically based estimator runs on the lane tracer
     auto pick = [&](auto tab_c) {
         constexpr bool TAB = decltype(tab_c)::value;
-        if constexpr (sizeof(R) == 8)
+        if (fast)
+        {
+            if constexpr (sizeof(R) == 8)
+            {
+                if constexpr (BRUTE)
+                    p.kernel = lights == 1 ? k_trace_fast_f64<true, TAB, 1> : k_trace_fast_f64<true, TAB, 2>;
+                else
+                    p.kernel = k_trace_fast_f64<false, TAB, 2>;
+            }
+            else
+            {
+                if constexpr (BRUTE)
+                    p.kernel = lights == 1 ? k_trace_fast_f32<true, TAB, 1> : k_trace_fast_f32<true, TAB, 2>;
+                else
+                    p.kernel = k_trace_fast_f32<false, TAB, 2>;
+            }
+        }
+        else if constexpr (sizeof(R) == 8)
         {
             if constexpr (BRUTE)
                 p.kernel = lights == 1 ? k_trace_f64<true, TAB, 1> : k_trace_f64<true, TAB, 2>;
@@ -684,7 +706,8 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
         pick(std::false_type());
     {
         char nm[96];
-        std::snprintf(nm, sizeof(nm), "k_trace_%s<%s, %s, %d>", sizeof(R) == 8 ? "f64" : "f32", BRUTE ? "true" : "false", tab ? "true" : "false", lights);
+        std::snprintf(nm, sizeof(nm), "k_trace_%s%s<%s, %s, %d>", fast ? "fast_" : "", sizeof(R) == 8 ? "f64" : "f32", BRUTE ? "true" : "false",
+                      tab ? "true" : "false", (fast && lights != 1) ? 2 : lights);
         p.name = nm;
     }
     if (!BRUTE && S.n_square <= 12 && rings)
@@ -834,6 +857,8 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     const int spp_total = o.spp_total > 0 ? o.spp_total : spp;
     if (depth > 65535)
         throw std::runtime_error("arg: depth above 65535 is not supported");
+    if (o.estimator != PTX_ESTIMATOR_REFERENCE_ && o.estimator != PTX_ESTIMATOR_FAST_)
+        throw std::runtime_error("arg: unknown estimator");
 
     // rows / columns inside DrawRegion (inclusive ends), clipped to the image
     int r0 = std::max(sc.region[0], 0), r1 = std::min(sc.region[2], sc.height - 1) + 1;
@@ -864,8 +889,9 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     DCamera cam = make_camera(sc);
     RenderTimers *tm = (o.profile && !static_state) ? &timers_ : nullptr;
     // The grid of the tracer is just large enough to fill the device: its waves are persistent.
-    const TracePlan<R> plan = brute_ ? plan_trace<R, true>(S, trace_blocks_per_cu, shadow_queue, 0, 0)
-                                    : plan_trace<R, false>(S, trace_blocks_per_cu, shadow_queue, geo_->stack_need, lds_stack_levels, bvh_rings);
+    const bool fast = o.estimator == PTX_ESTIMATOR_FAST_;
+    const TracePlan<R> plan = brute_ ? plan_trace<R, true>(S, trace_blocks_per_cu, shadow_queue, 0, 0, false, fast)
+                                    : plan_trace<R, false>(S, trace_blocks_per_cu, shadow_queue, geo_->stack_need, lds_stack_levels, bvh_rings, fast);
     last_kernel_ = plan.name;
 
     // ---- size the batch and the grid so that the state fits the memory there is --------------

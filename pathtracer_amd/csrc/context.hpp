@@ -13,6 +13,8 @@ namespace ptx
 
 constexpr int PTX_MODE_F64_ = 0;
 constexpr int PTX_MODE_F32_ = 1;
+constexpr int PTX_ESTIMATOR_REFERENCE_ = 0; // the reference's estimator: what parity is defined against
+constexpr int PTX_ESTIMATOR_FAST_ = 1;      // the physically based one (MIS, lobe sampling, roulette, shadowed sphere lights)
 
 struct RenderOpts
 {
@@ -25,6 +27,7 @@ struct RenderOpts
     int64_t batch_paths = 0;
     bool accumulate = false;
     bool profile = false;
+    int estimator = PTX_ESTIMATOR_REFERENCE_;
 };
 
 struct RenderStats

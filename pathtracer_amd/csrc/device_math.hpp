@@ -219,6 +219,9 @@ template <class R> __device__ __forceinline__ V3<R> barycentric(V3<R> p, V3<R> a
 // onto n with the quaternion of axis Y x (n - Y) and angle acos(n.y).  Same map here without inverse
 // trigonometry: cos theta = 1 - xi1, sin theta = sqrt(xi1 (2 - xi1)), and the rotation in Rodrigues
 // form with cos = n.y, sin = |(n.x, n.z)|, axis (n.z, 0, -n.x) / sin.
+// v, given about +Y, in the frame whose +Y is the unit vector n (the rotation about Y x n)
+template <class R> __device__ __forceinline__ V3<R> rotate_from_y(V3<R> n, V3<R> v);
+
 template <class R> __device__ __forceinline__ V3<R> sample_hemisphere(V3<R> n, R xi1, R xi2)
 {
 #pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
@@ -227,6 +230,12 @@ template <class R> __device__ __forceinline__ V3<R> sample_hemisphere(V3<R> n, R
     R sp, cp;
     sincospi_(R(2) * xi2, sp, cp);
     V3<R> v = {ct * cp, st, -ct * sp};
+    return rotate_from_y(n, v);
+}
+
+template <class R> __device__ __forceinline__ V3<R> rotate_from_y(V3<R> n, V3<R> v)
+{
+#pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
     R s2 = n.x * n.x + n.z * n.z;
     if (s2 > R(0))
     {
@@ -383,6 +392,190 @@ __device__ __forceinline__ R sphere_light_sample(const R *__restrict__ L, V3<R> 
     V3<R> lp = u * rad + C;
     rd = fast_normalized(ref - lp);
     return R(1) / (R(4) * pi);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The physically based estimator ("fast").  No counterpart in the reference (its estimator has no
+// sampling weights, no roulette and never shadows sphere lights, src/tracing/cBxDF.cpp:16-52,
+// src/tracing/cLight.cpp:216): BRDF f = Kd / pi + Ks (Ns + 2) / (2 pi) max(0, r.wi)^Ns sampled by
+// lobe (cosine hemisphere with probability pd = max Kd / (max Kd + max Ks), else the Phong lobe
+// about the mirror direction), glass as a delta lobe with the material's own Ni, every conf light
+// sampled with a visibility test and the balance heuristic against the BRDF's density, conf lights
+// as emitters that do not occlude for BRDF-sampled rays, Russian roulette from bounce 3 on.
+// Directions here are unit vectors pointing AWAY from the surface.
+// ---------------------------------------------------------------------------------------------
+template <class R> __device__ __forceinline__ R max3(R a, R b, R c) { return fmax(fmax(a, b), c); }
+
+// density (solid angle, from o along unit d) with which light L is sampled towards the point where
+// the ray (o, d) crosses it, and the distance to that point; 0 when the ray misses the light or
+// meets a square light from behind
+template <class R> __device__ __forceinline__ R fast_light_pdf(const R *__restrict__ L, V3<R> o, V3<R> d, R &t_out)
+{
+#pragma clang fp contract(fast)
+    const R pi = Consts<R>::pi;
+    t_out = Consts<R>::big;
+    if (L[0] == R(0))
+    {
+        const V3<R> P0 = {L[4], L[5], L[6]}, e10 = {L[7], L[8], L[9]}, e21 = {L[10], L[11], L[12]}, N = {L[13], L[14], L[15]};
+        const R dn = dot(d, N);
+        if (!(dn < R(0)))
+            return R(0);
+        const R t = dot(P0 - o, N) / dn;
+        if (!(t > Consts<R>::self_eps))
+            return R(0);
+        const V3<R> h = o + t * d - P0;
+        const R u = dot(h, e10) / dot(e10, e10), v = dot(h, e21) / dot(e21, e21);
+        if (u < R(0) || u > R(1) || v < R(0) || v > R(1))
+            return R(0);
+        t_out = t;
+        return t * t / (L[16] * -dn);
+    }
+    const V3<R> g = V3<R>{L[4], L[5], L[6]} - o;
+    const R rad = L[7];
+    const R dc2 = dot(g, g), b = dot(g, d), disc = b * b - dc2 + rad * rad;
+    if (!(disc >= R(0)))
+        return R(0);
+    const R sq = sqrt(disc);
+    if (dc2 > rad * rad)
+    {
+        const R t = b - sq;
+        if (!(t > Consts<R>::self_eps))
+            return R(0);
+        t_out = t;
+        return R(1) / (R(2) * pi * (R(1) - sqrt(R(1) - rad * rad / dc2)));
+    }
+    t_out = b + sq;
+    return R(1) / (R(4) * pi);
+}
+
+template <class R> __device__ __forceinline__ R fast_sphere_light_sample(const R *__restrict__ L, V3<R> p, R xi1, R xi2, V3<R> &wi, V3<R> &q);
+
+// one light sample from the shaded point p: unit direction wi towards the light, the point q on
+// the light, the density of wi (0: the sample is of no use)
+template <class R> __device__ __forceinline__ R fast_light_sample(const R *__restrict__ L, V3<R> p, R xi1, R xi2, V3<R> &wi, V3<R> &q)
+{
+    if (L[0] == R(0))
+    {
+        q = square_light_point(L, xi1, xi2); // unfused: a visibility test starts from this point
+        {
+#pragma clang fp contract(fast)
+            const V3<R> N = {L[13], L[14], L[15]};
+            const V3<R> w = q - p;
+            const R d2 = dot(w, w);
+            if (!(d2 > R(0)))
+                return R(0);
+            const R inv = rsqrt_(d2);
+            wi = {w.x * inv, w.y * inv, w.z * inv};
+            const R cl = -dot(wi, N);
+            if (!(cl > R(0)))
+                return R(0);
+            return d2 / (L[16] * cl);
+        }
+    }
+    return fast_sphere_light_sample(L, p, xi1, xi2, wi, q);
+}
+
+template <class R> __device__ __forceinline__ R fast_sphere_light_sample(const R *__restrict__ L, V3<R> p, R xi1, R xi2, V3<R> &wi, V3<R> &q)
+{
+#pragma clang fp contract(fast)
+    const R pi = Consts<R>::pi;
+    const V3<R> g = V3<R>{L[4], L[5], L[6]} - p;
+    const R rad = L[7];
+    const R dc2 = dot(g, g);
+    R sp, cp;
+    sincospi_(R(2) * xi2, sp, cp);
+    if (dc2 > rad * rad)
+    {
+        const R idc = rsqrt_(dc2), dc = dc2 * idc;
+        const V3<R> axis = {g.x * idc, g.y * idc, g.z * idc};
+        const R s2max = rad * rad / dc2, cmax = sqrt(R(1) - s2max);
+        const R ct = R(1) - xi1 * (R(1) - cmax), st2 = R(1) - ct * ct, st = sqrt(fmax(st2, R(0)));
+        wi = rotate_from_y(axis, V3<R>{st * cp, ct, -st * sp});
+        const R t = dc * ct - sqrt(fmax(rad * rad - dc2 * st2, R(0)));
+        q = {p.x + t * wi.x, p.y + t * wi.y, p.z + t * wi.z};
+        return R(1) / (R(2) * pi * (R(1) - cmax));
+    }
+    const R ct = R(1) - R(2) * xi1, st = sqrt(fmax(R(1) - ct * ct, R(0)));
+    wi = {st * cp, ct, -st * sp};
+    const R b = dot(g, wi), t = b + sqrt(b * b - dc2 + rad * rad);
+    q = {p.x + t * wi.x, p.y + t * wi.y, p.z + t * wi.z};
+    return R(1) / (R(4) * pi);
+}
+
+// BRDF value and sampling density of wi for the viewer direction wo about the normal n (n.wo >= 0)
+template <class R> __device__ __forceinline__ V3<R> fast_brdf(const R *__restrict__ m, V3<R> n, V3<R> wo, V3<R> wi, R &pdf)
+{
+#pragma clang fp contract(fast)
+    const R pi = Consts<R>::pi;
+    const R cn = dot(n, wi);
+    pdf = R(0);
+    if (!(cn > R(0)))
+        return V3<R>{R(0), R(0), R(0)};
+    const R k = R(2) * dot(n, wo);
+    const V3<R> r = {k * n.x - wo.x, k * n.y - wo.y, k * n.z - wo.z};
+    const R ca = dot(r, wi), ns = m[10];
+    R pw = R(0);
+    if (ca > R(0))
+        pw = (ns == R(1)) ? ca : (m[14] != R(0) ? pow_whole(ca, ns) : pow_outlined(ca, ns));
+    const R kd = max3(m[3], m[4], m[5]), ks = max3(m[6], m[7], m[8]);
+    const R ipi = R(1) / pi;
+    const R kk = (ns + R(2)) * (R(0.5) * ipi) * pw;
+    if (kd + ks > R(0))
+    {
+        const R pd = kd / (kd + ks);
+        pdf = pd * cn * ipi + (R(1) - pd) * ((ns + R(1)) * (R(0.5) * ipi)) * pw;
+    }
+    return V3<R>{m[3] * ipi + m[6] * kk, m[4] * ipi + m[7] * kk, m[5] * ipi + m[8] * kk};
+}
+
+// next direction of a BRDF surface from three draws; false: the path ends here
+template <class R> __device__ __forceinline__ bool fast_brdf_sample(const R *__restrict__ m, V3<R> n, V3<R> wo, R x0, R x1, R x2, V3<R> &wi)
+{
+#pragma clang fp contract(fast)
+    const R kd = max3(m[3], m[4], m[5]), ks = max3(m[6], m[7], m[8]), ns = m[10];
+    if (!(kd + ks > R(0)))
+        return false;
+    const R pd = kd / (kd + ks);
+    R sp, cp;
+    sincospi_(R(2) * x2, sp, cp);
+    if (x0 < pd)
+    {
+        const R r = sqrt(x1), h = sqrt(R(1) - x1);
+        wi = rotate_from_y(n, V3<R>{r * cp, h, -r * sp});
+    }
+    else
+    {
+        const R ca = pow_outlined(x1, R(1) / (ns + R(1))), sa = sqrt(fmax(R(1) - ca * ca, R(0)));
+        const R k = R(2) * dot(n, wo);
+        const V3<R> r = {k * n.x - wo.x, k * n.y - wo.y, k * n.z - wo.z};
+        wi = rotate_from_y(r, V3<R>{sa * cp, ca, -sa * sp});
+    }
+    return dot(n, wi) > R(0);
+}
+
+// glass: reflect or refract, chosen by Schlick's reflectance against one draw
+template <class R> __device__ __forceinline__ V3<R> fast_glass_sample(const R *__restrict__ m, V3<R> n, V3<R> wo, R xi)
+{
+#pragma clang fp contract(fast)
+    const R ni = m[9];
+    R ci = dot(n, wo), eta = R(1) / ni;
+    if (ci < R(0))
+    {
+        n = -n;
+        ci = -ci, eta = ni;
+    }
+    const R s2t = eta * eta * (R(1) - ci * ci);
+    bool refl = true;
+    R ct = R(0);
+    if (s2t < R(1))
+    {
+        ct = sqrt(R(1) - s2t);
+        const R c = eta > R(1) ? ct : ci, x = R(1) - c, x2 = x * x;
+        const R Rf = m[11] + (R(1) - m[11]) * (x2 * x2 * x);
+        refl = xi < Rf;
+    }
+    const R a = refl ? R(2) * ci : eta * ci - ct, b = refl ? R(1) : eta;
+    return V3<R>{a * n.x - b * wo.x, a * n.y - b * wo.y, a * n.z - b * wo.z};
 }
 
 } // namespace ptx

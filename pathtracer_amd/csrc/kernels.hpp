@@ -90,7 +90,7 @@ __device__ __forceinline__ int local_row_to_image_row(const DBatch &b, int lr)
 // f32), aligned, so that a record is one memory sector however the slots are handed out
 constexpr int REC_STRIDE = 8;
 constexpr int LANE_SLOTS = 192; // record slots of a wave of the lane tracers: 64 paths on the lanes + at most 127 awaiting their resolve pass
-constexpr int RING_SLOTS = 320; // of the ring tracer: at most 192 paths in flight + 127 awaiting their resolve pass
+constexpr int RING_SLOTS = 512; // of the ring tracer: 8 generations of 64 (at most 192 paths in flight + 127 awaiting their resolve pass)
 
 // per-batch device state.  pid = sample_local * n_pix + pixel_local numbers the paths of a batch.
 template <class R> struct DState
@@ -816,7 +816,14 @@ struct DoneQueue
 // and to starting new paths -- when enough lanes are waiting for it.  Lanes with a long traversal
 // simply keep going while the others shade, start their next ray and catch up.  (BVH scenes
 // without square lights use the ring tracer of bvh_tracer.hpp instead.)
-template <class R, bool BRUTE, bool TAB, int LIGHTS>
+//
+// FAST: the physically based estimator (device_math.hpp, "fast") on the same machinery.  A lane
+// also carries its path's throughput and the density its current direction was sampled with; the
+// record of a bounce holds (light-sampling term, everything else the bounce collects: conf lights
+// its ray crossed, an emitter the camera sees), both already multiplied by the throughput, every
+// segment writes one, a blocked visibility test still only zeroes the first half, and the
+// resolve pass is a plain sum.  Every light needs its visibility test here, sphere lights too.
+template <class R, bool BRUTE, bool TAB, int LIGHTS, bool FAST = false>
 __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &cam, const DBatch &B, const DState<R> &st, int chunk)
 {
     constexpr bool NRM = BRUTE; // all-triangles intersector = at most 64 triangles: the per-triangle tables fit LDS
@@ -881,6 +888,10 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
     uint64_t key = 0;
     uint32_t n_seg = 0, n_tests = 0, n_iter = 0, n_rec = 0;
     uint32_t n_visit[2] = {0, 0}; // BVH node / triangle records visited by this lane
+    // FAST: throughput of the path so far, and the density (solid angle) its current direction was
+    // sampled with -- -1 after a delta lobe, -2 while only delta lobes lie between it and the camera
+    V3<R> thr = {R(1), R(1), R(1)};
+    R pdf_prev = R(-2);
 
     // tests the first n (<= 64) parked segments, one per lane, and removes the direct light of
     // the blocked ones from their bounce records
@@ -911,8 +922,15 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                     L0 = lds_lights;
                 else
                     L0 = S.lights;
-                const V3<R> a = square_light_point(L0, sq.xi[0][e], sq.xi[1][e]); // same point as at shading time
                 const V3<R> b = {sq.p2[0][e], sq.p2[1][e], sq.p2[2][e]};
+                V3<R> a; // the light point, recomputed from the draws: same bits as at shading time
+                if constexpr (FAST)
+                {
+                    V3<R> unused;
+                    (void)fast_light_sample(L0, b, sq.xi[0][e], sq.xi[1][e], unused, a);
+                }
+                else
+                    a = square_light_point(L0, sq.xi[0][e], sq.xi[1][e]);
                 const uint32_t ob = sq.own_bounce[e];
                 if (!visible<R, BRUTE>(S, a, b, stk, int(ob >> 16), blockers))
                 {
@@ -984,6 +1002,12 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 const int i = top - k;
                 if (i >= 0 && i < len)
                 {
+                    if constexpr (FAST)
+                    {
+                        // every term already carries its throughput: the path's radiance is their sum
+                        fr += q[k][0] + q[k][3], fg += q[k][1] + q[k][4], fb += q[k][2] + q[k][5];
+                        continue;
+                    }
                     fr = q[k][0] + q[k][3] * fr;
                     fg = q[k][1] + q[k][4] * fg;
                     fb = q[k][2] + q[k][5] * fb;
@@ -1099,6 +1123,8 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 sample = uint32_t(B.sample0) + pid / n_pix;
                 bounce = 0, prim = -1;
                 alive = true;
+                if constexpr (FAST)
+                    thr = {R(1), R(1), R(1)}, pdf_prev = R(-2);
                 if constexpr (!BRUTE)
                     trav_init(T, o, d), trav_done = false;
             }
@@ -1114,6 +1140,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         // ---- closest hit and the termination rules (miss / no material -> tail 0; emitter -> Ka) --
         bool shaded = false, finished = false; // finished: this lane's path ended in this iteration
         uint32_t fin_state = 0;
+        V3<R> fast_other = {R(0), R(0), R(0)}; // FAST: what this segment collected besides light sampling
         V3<R> p = {R(0), R(0), R(0)};
         int hit_k = -1;
         const R *m = nullptr; // the address space (LDS or global) is fixed at compile time
@@ -1133,7 +1160,44 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             else
                 m = S.mats + mrow;
             alive = false;
-            if (mat_id < 0)
+            if constexpr (FAST)
+            {
+                // conf lights this ray crossed before its hit: emitters that do not occlude, seen by
+                // sampled directions only (not by the camera or through delta lobes from it)
+                V3<R> other = {R(0), R(0), R(0)};
+                if (pdf_prev > R(-2))
+                {
+                    const R t_geom = hit_k >= 0 ? norm(p - o) : Consts<R>::big;
+                    for (int l = 0; l < S.n_lights; l++)
+                    {
+                        const R *L;
+                        if constexpr (TAB)
+                            L = lds_lights + l * LIGHT_STRIDE;
+                        else
+                            L = S.lights + (size_t)l * LIGHT_STRIDE;
+                        R tl;
+                        const R pl = fast_light_pdf(L, o, d, tl);
+                        if (pl > R(0) && tl < t_geom)
+                        {
+                            const R w = pdf_prev < R(0) ? R(1) : pdf_prev / (pdf_prev + pl);
+                            other = other + V3<R>{thr.x * L[1] * w, thr.y * L[2] * w, thr.z * L[3] * w};
+                        }
+                    }
+                }
+                fast_other = other;
+                if (mat_id < 0 || m[13] != R(0))
+                {
+                    // the path ends here; an emitter counts when the camera sees it
+                    if (mat_id >= 0 && pdf_prev == R(-2))
+                        other = other + V3<R>{thr.x * m[0], thr.y * m[1], thr.z * m[2]};
+                    store_record(record_at(st, g, slot, depth, uint32_t(bounce)), V3<R>{R(0), R(0), R(0)}, other);
+                    n_rec++;
+                    finished = true, fin_state = uint32_t(bounce + 1) << 16;
+                }
+                else
+                    shaded = true;
+            }
+            else if (mat_id < 0)
                 finished = true, fin_state = uint32_t(bounce) << 16;
             else if (m[13] != R(0))
                 finished = true, fin_state = (uint32_t(bounce) << 16) | uint32_t(mat_id + 1);
@@ -1144,7 +1208,121 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         bool park = false; // this lane has a visibility test for the queue
         R park_x1 = R(0), park_x2 = R(0);
         const uint32_t seg_pid = pid, seg_bounce = uint32_t(bounce), seg_slot = slot;
-        if (shaded)
+        if constexpr (FAST)
+        {
+            if (shaded)
+            {
+                const V3<R> wo = -d;
+                // ---- shading normal, as below ------------------------------------------------------------
+                R fn0, fn1, fn2, fn3;
+                if (NRM)
+                    fn0 = lds_nrm[hit_k * 4], fn1 = lds_nrm[hit_k * 4 + 1], fn2 = lds_nrm[hit_k * 4 + 2], fn3 = lds_nrm[hit_k * 4 + 3];
+                else
+                {
+                    const R *__restrict__ fn = S.tri_nrm + (size_t)hit_k * 4;
+                    fn0 = fn[0], fn1 = fn[1], fn2 = fn[2], fn3 = fn[3];
+                }
+                V3<R> nrm = {fn0, fn1, fn2};
+                if (fn3 == R(0))
+                {
+                    const int face = S.tri_face[hit_k];
+                    const Float9 fv = load9(S.verts + (size_t)face * 9), fq = load9(S.normals + (size_t)face * 9);
+                    V3<R> a = {R(fv.v[0]), R(fv.v[1]), R(fv.v[2])}, b = {R(fv.v[3]), R(fv.v[4]), R(fv.v[5])}, c = {R(fv.v[6]), R(fv.v[7]), R(fv.v[8])};
+                    V3<R> w = barycentric(p, a, b, c);
+                    V3<R> acc = w.x * V3<R>{R(fq.v[0]), R(fq.v[1]), R(fq.v[2])};
+                    acc = acc + w.y * V3<R>{R(fq.v[3]), R(fq.v[4]), R(fq.v[5])};
+                    acc = acc + w.z * V3<R>{R(fq.v[6]), R(fq.v[7]), R(fq.v[8])};
+                    nrm = fast_normalized(acc);
+                }
+                const int D0 = 4 * S.n_lights;
+                V3<R> direct = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
+                bool go_on = S.enable_indirect != 0;
+                if (m[12] != R(0))
+                {
+                    // glass: a delta lobe, no light sampling
+                    if (go_on)
+                    {
+                        wi = fast_glass_sample(m, nrm, wo, rng_draw<R>(key, sample, bounce, D0));
+                        pdf_prev = pdf_prev == R(-2) ? R(-2) : R(-1);
+                    }
+                }
+                else
+                {
+                    if (dot(nrm, wo) < R(0))
+                        nrm = -nrm;
+                    for (int l = 0; l < S.n_lights; l++)
+                    {
+                        const R *L;
+                        if constexpr (TAB)
+                            L = lds_lights + l * LIGHT_STRIDE;
+                        else
+                            L = S.lights + (size_t)l * LIGHT_STRIDE;
+                        const R x1 = rng_draw<R>(key, sample, bounce, 4 * l + 0);
+                        const R x2 = rng_draw<R>(key, sample, bounce, 4 * l + 1);
+                        V3<R> wl, q;
+                        const R pl = fast_light_sample(L, p, x1, x2, wl, q);
+                        if (!(pl > R(0)))
+                            continue;
+                        R pb;
+                        const V3<R> f = fast_brdf(m, nrm, wo, wl, pb);
+                        const R cn = dot(nrm, wl);
+                        if (!(cn > R(0)))
+                            continue;
+                        n_tests++;
+                        if constexpr (SQ1)
+                            park = true, park_x1 = x1, park_x2 = x2; // the term counts unless the test fails later
+                        else
+                        {
+                            if (!visible<R, BRUTE>(S, q, p, stk, hit_k, 0xFFFFFFFFu, n_visit))
+                                continue;
+                        }
+                        // cos / pl times the balance weight pl / (pl + pb); at the last bounce no sampled
+                        // direction follows that could collect the other share: the light sample counts whole
+                        const R w = (go_on && bounce + 1 < depth) ? cn / (pl + pb) : cn / pl;
+                        direct = direct + V3<R>{thr.x * L[1] * f.x * w, thr.y * L[2] * f.y * w, thr.z * L[3] * f.z * w};
+                    }
+                    if (go_on)
+                    {
+                        const R x0 = rng_draw<R>(key, sample, bounce, D0), x1 = rng_draw<R>(key, sample, bounce, D0 + 1);
+                        const R x2 = rng_draw<R>(key, sample, bounce, D0 + 2);
+                        go_on = fast_brdf_sample(m, nrm, wo, x0, x1, x2, wi);
+                        if (go_on)
+                        {
+                            R pb;
+                            const V3<R> f = fast_brdf(m, nrm, wo, wi, pb);
+                            go_on = pb > R(0);
+                            if (go_on)
+                            {
+                                const R c = dot(nrm, wi) / pb;
+                                thr = {thr.x * (f.x * c), thr.y * (f.y * c), thr.z * (f.z * c)};
+                                pdf_prev = pb;
+                            }
+                        }
+                    }
+                }
+                store_record(record_at(st, g, slot, depth, uint32_t(bounce)), direct, fast_other);
+                n_rec++;
+                // Russian roulette from bounce 3 on
+                if (go_on && bounce >= 3)
+                {
+                    const R q = fmin(max3(thr.x, thr.y, thr.z), R(0.95));
+                    go_on = rng_draw<R>(key, sample, bounce, D0 + 3) < q;
+                    if (go_on)
+                        thr = {thr.x / q, thr.y / q, thr.z / q};
+                }
+                if (go_on && bounce + 1 < depth)
+                {
+                    o = p, d = wi, prim = hit_k;
+                    bounce++;
+                    alive = true;
+                    if constexpr (!BRUTE)
+                        trav_init(T, o, d), trav_done = false;
+                }
+                else
+                    finished = true, fin_state = uint32_t(bounce + 1) << 16;
+            }
+        }
+        else if (shaded)
         {
             // ---- shading normal: precomputed per triangle when it is flat (its three vertex normals
             // are equal) or when barycentric normals are off; else interpolated ---------------------
@@ -1309,6 +1487,18 @@ template <bool BRUTE, bool TAB, int LIGHTS>
 __global__ void __launch_bounds__(BLOCK, BRUTE ? 4 : 3) k_trace_f32(DScene<float> S, DCamera cam, DBatch B, DState<float> st, int chunk)
 {
     trace_body<float, BRUTE, TAB, LIGHTS>(S, cam, B, st, chunk);
+}
+// the physically based estimator on the same tracer (LIGHTS: 1 -- one light, its tests parked;
+// 2 -- tests in place; 0 -- no light)
+template <bool BRUTE, bool TAB, int LIGHTS>
+__global__ void __launch_bounds__(BLOCK, 2) k_trace_fast_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
+{
+    trace_body<double, BRUTE, TAB, LIGHTS, true>(S, cam, B, st, chunk);
+}
+template <bool BRUTE, bool TAB, int LIGHTS>
+__global__ void __launch_bounds__(BLOCK, 3) k_trace_fast_f32(DScene<float> S, DCamera cam, DBatch B, DState<float> st, int chunk)
+{
+    trace_body<float, BRUTE, TAB, LIGHTS, true>(S, cam, B, st, chunk);
 }
 
 } // namespace ptx

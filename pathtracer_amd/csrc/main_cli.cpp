@@ -21,7 +21,7 @@ int main(int argc, char **argv)
     if (argc < 2)
     {
         std::printf("[error] usage: pathtracer <conf> [--width W] [--height H] [--spp N] [--depth D] [--out PATH] "
-                    "[--mode f64|f32] [--gpu ID] [--seed S] [--root DIR] [--model OBJ]\n"
+                    "[--mode f64|f32] [--estimator reference|fast] [--gpu ID] [--seed S] [--root DIR] [--model OBJ]\n"
                     "        several GPUs of this node: [--gpus N | --devices ID,ID,...] [--scheme bands|samples] "
                     "[--exchange rccl|peer]\n");
         return 1;
@@ -82,6 +82,8 @@ int main(int argc, char **argv)
             ro.seed = std::strtoull(next(), nullptr, 10);
         else if (a == "--mode")
             ro.mode = std::string(next()) == "f32" ? PTX_MODE_F32 : PTX_MODE_F64;
+        else if (a == "--estimator")
+            ro.estimator = std::string(next()) == "fast" ? PTX_ESTIMATOR_FAST : PTX_ESTIMATOR_REFERENCE;
         else
         {
             std::printf("[error] unknown option %s\n", a.c_str());

@@ -277,3 +277,21 @@ def test_bvh_oracle_equals_brute_force(root):
     ib, pb = b.first_hit(with_points=True)
     assert np.array_equal(ia, ib) and np.array_equal(pa, pb, equal_nan=True)
     assert np.array_equal(a.render(), b.render())
+
+
+def test_fast_estimator_strategies_agree_in_the_mean(root):
+    """The physically based estimator of the oracle: light sampling alone, BRDF sampling alone and
+    their balance-heuristic combination are three estimators of the same integral wherever no delta
+    lobe is involved -- which pins the light densities (square: area -> solid angle; sphere: cone)
+    against the BRDF's (cosine + Phong lobe) and against the ray / light intersections."""
+    for conf, w, h in (("config/mis.conf", 16, 12), ("config/cbox_glossy.conf", 16, 16)):
+        ref = scene_io.load_conf(os.path.join(root, conf), root_dir=root, width=w, height=h, spp=4096, depth=4)
+        ref.mats = ref.mats.copy()
+        ref.mats[:, 9] = 1.0                                     # no glass: every lobe has a density
+        m = [oracle.Oracle(ref, seed=13, estimator="fast", fast_strategy=k).render().mean(axis=(0, 1)) for k in (0, 1, 2)]
+        assert np.abs(m[1] / m[0] - 1).max() < 0.02, conf
+        # BRDF sampling alone rarely finds the small, bright sphere lights of mis: a noisy mean
+        assert np.abs(m[2] / m[0] - 1).max() < (0.1 if "mis" in conf else 0.03), conf
+        # and it is not the reference's estimator (whose light sampling is 2 pi too bright in the Cornell box)
+        if "cbox" in conf:
+            assert oracle.Oracle(ref, seed=13).render().mean() > 1.5 * m[0].mean()
