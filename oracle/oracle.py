@@ -37,14 +37,25 @@ class OrcStats(C.Structure):
 
 
 _lib = None
+_variant = 0
+
+
+def use_sum_order(variant):
+    """Switches every later oracle call of this process to the restatement built with ORC_SUM =
+    variant (0: left-to-right sums, the default; 1, 2: the other plausible Eigen orders)."""
+    global _lib, _variant
+    if variant != _variant:
+        _lib, _variant = None, int(variant)
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            raise RuntimeError("oracle/liboracle.so missing: run `make -C oracle`")
-        L = C.CDLL(_LIB_PATH)
+        path = _LIB_PATH if _variant == 0 else os.path.join(_HERE, "liboracle_sum%d.so" % _variant)
+        if not os.path.exists(path):
+            raise RuntimeError("%s missing: run `make -C oracle`" % path)
+        L = C.CDLL(path)
+        assert L.orc_sum_order() == _variant
         L.orc_rng.restype = C.c_double
         L.orc_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_rng_bits.restype = C.c_uint64

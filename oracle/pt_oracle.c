@@ -32,6 +32,32 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+/* Order of the additions in the 3- and 4-term sums of the hot path (dot products, determinant,
+ * row x vector, squared norms).  The reference leaves it to Eigen, whose source is not in its
+ * checkout; the plausible orders are a build-time switch so that their effect can be counted
+ * (tools/sum_order_report.py):
+ *   ORC_SUM 0  left to right            (a + b) + c          ((a + b) + c) + d      -- the default
+ *   ORC_SUM 1  last two first           a + (b + c)          (a + b) + (c + d)      -- Eigen's unrolled scalar redux
+ *   ORC_SUM 2  as 2-wide packets        a + (b + c)          (a + c) + (b + d)      -- Eigen's vectorised redux of a
+ *                                                                                       4-vector (points carry w = 0 or 1) */
+#ifndef ORC_SUM
+#define ORC_SUM 0
+#endif
+#if ORC_SUM == 0
+#define SUM3(a, b, c) (((a) + (b)) + (c))
+#define SUM4(a, b, c, d) ((((a) + (b)) + (c)) + (d))
+#define SQ4(x, y, z) (((x) + (y)) + (z)) /* squared norm of a 4-vector whose w is 0 */
+#elif ORC_SUM == 1
+#define SUM3(a, b, c) ((a) + ((b) + (c)))
+#define SUM4(a, b, c, d) (((a) + (b)) + ((c) + (d)))
+#define SQ4(x, y, z) (((x) + (y)) + (z)) /* (x + y) + (z + 0) */
+#else
+#define SUM3(a, b, c) ((a) + ((b) + (c)))
+#define SUM4(a, b, c, d) (((a) + (c)) + ((b) + (d)))
+#define SQ4(x, y, z) (((x) + (z)) + (y)) /* (x + z) + (y + 0) */
+#endif
+int orc_sum_order(void) { return ORC_SUM; }
+
 /* ------------------------------------------------------------------------------------------ */
 /* scene description handed over by the Python front end (flat arrays, all double / int32)      */
 /* ------------------------------------------------------------------------------------------ */
@@ -112,7 +138,7 @@ double orc_rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, 
 /* ------------------------------------------------------------------------------------------ */
 static inline double dot3(const double *a, const double *b)
 {
-    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    return SUM3(a[0] * b[0], a[1] * b[1], a[2] * b[2]);
 }
 static inline void cross3(const double *a, const double *b, double *o)
 {
@@ -121,11 +147,11 @@ static inline void cross3(const double *a, const double *b, double *o)
     double z = a[0] * b[1] - a[1] * b[0];
     o[0] = x, o[1] = y, o[2] = z;
 }
-static inline double norm3(const double *a) { return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+static inline double norm3(const double *a) { return sqrt(SQ4(a[0] * a[0], a[1] * a[1], a[2] * a[2])); }
 /* Eigen normalized(): divides by the norm when squaredNorm > 0, else returns the vector as is */
 static inline void normalize3(const double *a, double *o)
 {
-    double z = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+    double z = SQ4(a[0] * a[0], a[1] * a[1], a[2] * a[2]);
     if (z > 0)
     {
         double n = sqrt(z);
@@ -145,7 +171,7 @@ static void inverse3(const double *m, double *inv)
     double c00 = m[4] * m[8] - m[5] * m[7];
     double c10 = m[7] * m[2] - m[8] * m[1];
     double c20 = m[1] * m[5] - m[2] * m[4];
-    double det = c00 * m[0] + c10 * m[3] + c20 * m[6];
+    double det = SUM3(c00 * m[0], c10 * m[3], c20 * m[6]);
     double id = 1.0 / det;
     inv[0] = c00 * id, inv[1] = c10 * id, inv[2] = c20 * id;
     inv[3] = (m[5] * m[6] - m[3] * m[8]) * id;
@@ -173,9 +199,9 @@ static inline int tri_solve(const double *o, const double *d, const double *p1, 
         r[i] = p1[i] - o[i];
     }
     inverse3(m, inv);
-    double beta = inv[0] * r[0] + inv[1] * r[1] + inv[2] * r[2];
-    double gamma = inv[3] * r[0] + inv[4] * r[1] + inv[5] * r[2];
-    double t = inv[6] * r[0] + inv[7] * r[1] + inv[8] * r[2];
+    double beta = SUM3(inv[0] * r[0], inv[1] * r[1], inv[2] * r[2]);
+    double gamma = SUM3(inv[3] * r[0], inv[4] * r[1], inv[5] * r[2]);
+    double t = SUM3(inv[6] * r[0], inv[7] * r[1], inv[8] * r[2]);
     double alpha = 1 - beta - gamma;
     if (0 - eps < alpha && alpha < 1 + eps && 0 - eps < beta && beta < 1 + eps && 0 - eps < gamma &&
         gamma < 1 + eps && t > 0 - eps)
@@ -581,7 +607,7 @@ void orc_barycentric(const double *p_, const double *a, const double *b, const d
     inverse3(A, inv);
     double r[3];
     for (int i = 0; i < 3; i++)
-        r[i] = inv[i * 3 + 0] * p[0] + inv[i * 3 + 1] * p[1] + inv[i * 3 + 2] * p[2];
+        r[i] = SUM3(inv[i * 3 + 0] * p[0], inv[i * 3 + 1] * p[1], inv[i * 3 + 2] * p[2]);
     normalize3(r, w);
 }
 
@@ -833,11 +859,8 @@ static void mat4_mul(const double *a, const double *b, double *o)
     for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++)
         {
-            double s = a[i * 4 + 0] * b[0 * 4 + j];
-            s += a[i * 4 + 1] * b[1 * 4 + j];
-            s += a[i * 4 + 2] * b[2 * 4 + j];
-            s += a[i * 4 + 3] * b[3 * 4 + j];
-            r[i * 4 + j] = s;
+            r[i * 4 + j] = SUM4(a[i * 4 + 0] * b[0 * 4 + j], a[i * 4 + 1] * b[1 * 4 + j], a[i * 4 + 2] * b[2 * 4 + j],
+                                a[i * 4 + 3] * b[3 * 4 + j]);
         }
     memcpy(o, r, sizeof(r));
 }
@@ -878,7 +901,7 @@ static void mat4_inverse(const double *m, double *inv)
             m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
     a[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] +
             m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
-    double det = m[0] * a[0] + m[1] * a[4] + m[2] * a[8] + m[3] * a[12];
+    double det = SUM4(m[0] * a[0], m[1] * a[4], m[2] * a[8], m[3] * a[12]);
     double id = 1.0 / det;
     for (int i = 0; i < 16; i++)
         inv[i] = a[i] * id;
@@ -909,11 +932,7 @@ static void primary_ray(const orc_scene *sc, const double *mat, int x, int y, do
     double v[4] = {(double)x, (double)y, 1, 1}, pos[3];
     for (int i = 0; i < 3; i++)
     {
-        double s = mat[i * 4 + 0] * v[0];
-        s += mat[i * 4 + 1] * v[1];
-        s += mat[i * 4 + 2] * v[2];
-        s += mat[i * 4 + 3] * v[3];
-        pos[i] = s;
+        pos[i] = SUM4(mat[i * 4 + 0] * v[0], mat[i * 4 + 1] * v[1], mat[i * 4 + 2] * v[2], mat[i * 4 + 3] * v[3]);
     }
     double g[3] = {pos[0] - sc->cam_pos[0], pos[1] - sc->cam_pos[1], pos[2] - sc->cam_pos[2]};
     normalize3(g, d);

@@ -111,50 +111,55 @@ struct Builder
         }
         else if (ext > 0)
         {
-            constexpr int NB = 16;
-            Box bb[NB];
-            int bc[NB] = {0};
-            const double k1 = NB * (1 - 1e-9) / ext;
-            for (int i = first; i < first + count; i++)
-            {
-                int b = static_cast<int>((centroid[order[i] * 3 + axis] - cb.lo[axis]) * k1);
-                b = std::min(std::max(b, 0), NB - 1);
-                bb[b].grow(tri_box[order[i]]);
-                bc[b]++;
-            }
-            double left_area[NB], right_area[NB];
-            int left_cnt[NB], right_cnt[NB];
-            Box acc;
-            int c = 0;
-            for (int b = 0; b < NB; b++)
-            {
-                acc.grow(bb[b]);
-                c += bc[b];
-                left_area[b] = acc.area(), left_cnt[b] = c;
-            }
-            acc = Box();
-            c = 0;
-            for (int b = NB - 1; b >= 0; b--)
-            {
-                acc.grow(bb[b]);
-                c += bc[b];
-                right_area[b] = acc.area(), right_cnt[b] = c;
-            }
+            // surface-area heuristic over binned centroids, all three axes: the split with the
+            // smallest  area(left) * count(left) + area(right) * count(right)
+            constexpr int NB = 32;
             double best = std::numeric_limits<double>::infinity();
-            int best_b = -1;
-            for (int b = 0; b < NB - 1; b++)
+            int best_b = -1, best_axis = axis;
+            double best_k1 = 0;
+            for (int ax = 0; ax < 3; ax++)
             {
-                if (left_cnt[b] == 0 || right_cnt[b + 1] == 0)
+                const double e = cb.hi[ax] - cb.lo[ax];
+                if (!(e > 0))
                     continue;
-                double cost = left_area[b] * left_cnt[b] + right_area[b + 1] * right_cnt[b + 1];
-                if (cost < best)
-                    best = cost, best_b = b;
+                Box bb[NB];
+                int bc[NB] = {0};
+                const double k1 = NB * (1 - 1e-9) / e;
+                for (int i = first; i < first + count; i++)
+                {
+                    int b = static_cast<int>((centroid[order[i] * 3 + ax] - cb.lo[ax]) * k1);
+                    b = std::min(std::max(b, 0), NB - 1);
+                    bb[b].grow(tri_box[order[i]]);
+                    bc[b]++;
+                }
+                double right_area[NB];
+                int right_cnt[NB];
+                Box acc;
+                int c = 0;
+                for (int b = NB - 1; b >= 0; b--)
+                {
+                    acc.grow(bb[b]);
+                    c += bc[b];
+                    right_area[b] = acc.area(), right_cnt[b] = c;
+                }
+                acc = Box();
+                c = 0;
+                for (int b = 0; b < NB - 1; b++)
+                {
+                    acc.grow(bb[b]);
+                    c += bc[b];
+                    if (c == 0 || right_cnt[b + 1] == 0)
+                        continue;
+                    const double cost = acc.area() * c + right_area[b + 1] * right_cnt[b + 1];
+                    if (cost < best)
+                        best = cost, best_b = b, best_axis = ax, best_k1 = k1;
+                }
             }
             if (best_b >= 0)
             {
-                const double lo = cb.lo[axis];
+                const double lo = cb.lo[best_axis];
                 auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](int32_t t) {
-                    int b = static_cast<int>((centroid[t * 3 + axis] - lo) * k1);
+                    int b = static_cast<int>((centroid[t * 3 + best_axis] - lo) * best_k1);
                     b = std::min(std::max(b, 0), NB - 1);
                     return b <= best_b;
                 });

@@ -38,9 +38,7 @@ constexpr int RING_BATCH = 40;      // lanes that hand over hits / take rays tog
 
 // bytes of one wave's two rings and of its per-slot path table
 template <class R> constexpr size_t ring_bytes() { return size_t(RING_CAP) * (12 * sizeof(R) + 4 * 7) + size_t(RING_SLOTS) * 12; }
-// Record slots of a wave are handed out a generation (64 slots, one per lane) at a time, to the 64
-// camera rays that enter together; a generation is free again once all its paths are resolved.
-constexpr int RING_GENS = RING_SLOTS / 64;
+
 
 // views of the two rings of one wave (structure of arrays: one field of 256 entries after the
 // other) and of its path table.  What a path is -- its id and the key of its random numbers --
@@ -94,6 +92,9 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     __shared__ R lds_mats[TAB ? LDS_MATS * MAT_STRIDE : 1];
     __shared__ R lds_lights[TAB ? LDS_LIGHTS * LIGHT_STRIDE : 1];
     __shared__ DoneQueue done_queues[BLOCK / 64];
+    __shared__ uint16_t free_slots[BLOCK / 64][RING_SLOTS]; // per wave: the record slots no path holds (a stack)
+    for (int k = threadIdx.x; k < (BLOCK / 64) * RING_SLOTS; k += BLOCK)
+        free_slots[k / RING_SLOTS][k % RING_SLOTS] = uint16_t(k % RING_SLOTS);
     if (TAB)
     {
         for (int k = threadIdx.x; k < S.n_mats * MAT_STRIDE; k += BLOCK)
@@ -116,12 +117,11 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     DoneQueue &dq = done_queues[threadIdx.x >> 6];
     uint32_t dq_head = 0, dq_count = 0;               // wave-uniform
     uint32_t rq_head = 0, rq_count = 0, hq_head = 0, hq_count = 0; // wave-uniform
-    // record slots: paths not yet resolved per generation (wave-uniform: scalar registers)
-    uint32_t gen_live[RING_GENS];
-#pragma unroll
-    for (int k = 0; k < RING_GENS; k++)
-        gen_live[k] = 0u;
-    uint32_t slot = 0; // of the path whose ray this lane traverses
+    // record slots: a path takes one when its camera ray is admitted and returns it in its resolve
+    // pass; at most 192 paths are in flight and at most 127 wait in dq, so the stack never runs dry
+    uint16_t *free_slot = free_slots[threadIdx.x >> 6];
+    uint32_t free_count = RING_SLOTS; // wave-uniform
+    uint32_t slot = 0;                // of the path whose ray this lane traverses
 
     // the ray this lane is traversing
     bool busy = false, done = false; // done: traversal complete, the hit waits to be handed over
@@ -196,21 +196,17 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             }
         }
         if (mine)
+        {
             st.result[rp] = fr, st.result[st.N + rp] = fg, st.result[2 * st.N + rp] = fb;
-#pragma unroll
-        for (int k = 0; k < RING_GENS; k++)
-            gen_live[k] -= uint32_t(__popcll(__ballot(mine && int(rslot >> 6) == k)));
+            free_slot[free_count + uint32_t(lane)] = uint16_t(rslot); // the slots go back on the stack
+        }
+        free_count += n;
         dq_head = (dq_head + n) % DoneQueue::CAP;
         dq_count -= n;
-    };
-
-    // a generation of record slots no path holds (-1: none)
-    auto free_gen = [&]() {
-        int gen = -1;
-#pragma unroll
-        for (int k = RING_GENS - 1; k >= 0; k--)
-            gen = gen_live[k] == 0u ? k : gen;
-        return gen;
+        // the next camera rays read the stack the lanes above just wrote
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
     // shades the first n (<= 64) hits of the hit ring, one per lane
@@ -419,17 +415,12 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             n_busy -= __popcll(gm);
         }
         // ---- 64 hits wait: shade them (fewer only when nothing else is left to do) -----------------
-        // (or when no generation of record slots is free and only shading can finish paths)
         if (hq_count >= 64u)
             shade(64u);
-        else if (hq_count > 0u && n_busy == 0 && rq_count == 0u && (drained || free_gen() < 0))
+        else if (hq_count > 0u && n_busy == 0 && rq_count == 0u && drained)
             shade(hq_count);
         // ---- camera rays enter through the ray ring, 64 at a time ----------------------------------
-        const int gen = free_gen();
-        const bool admit = !drained && rq_count < 64u && rq_count + hq_count + uint32_t(n_busy) <= uint32_t(RING_ADMIT);
-        if (admit && gen < 0 && dq_count > 0u)
-            resolve(dq_count < 64u ? dq_count : 64u); // every generation has a path left: finish what waits (rare)
-        if (admit && gen >= 0)
+        if (!drained && rq_count < 64u && rq_count + hq_count + uint32_t(n_busy) <= uint32_t(RING_ADMIT))
         {
             if (next == end)
             {
@@ -455,15 +446,13 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 const uint32_t r = (rq_head + rq_count + uint32_t(lane)) % RING_CAP;
                 Q.ro[r] = cam_pos.x, Q.ro[RING_CAP + r] = cam_pos.y, Q.ro[2 * RING_CAP + r] = cam_pos.z;
                 Q.rd[r] = cd.x, Q.rd[RING_CAP + r] = cd.y, Q.rd[2 * RING_CAP + r] = cd.z;
-                const uint32_t sl = uint32_t(gen) * 64u + uint32_t(lane);
+                const uint32_t sl = free_slot[free_count - 1u - uint32_t(lane)];
                 Q.r_slot[r] = sl, Q.r_bounce[r] = 0u;
                 Q.s_pid[sl] = id, Q.s_klo[sl] = uint32_t(key), Q.s_khi[sl] = uint32_t(key >> 32);
                 if (SQ)
                     Q.r_light[r] = -1;
             }
-#pragma unroll
-            for (int k = 0; k < RING_GENS; k++)
-                gen_live[k] += k == gen ? cnt : 0u;
+            free_count -= cnt;
             next += cnt;
             rq_count += cnt;
         }

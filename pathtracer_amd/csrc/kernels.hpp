@@ -90,7 +90,7 @@ __device__ __forceinline__ int local_row_to_image_row(const DBatch &b, int lr)
 // f32), aligned, so that a record is one memory sector however the slots are handed out
 constexpr int REC_STRIDE = 8;
 constexpr int LANE_SLOTS = 192; // record slots of a wave of the lane tracers: 64 paths on the lanes + at most 127 awaiting their resolve pass
-constexpr int RING_SLOTS = 512; // of the ring tracer: 8 generations of 64 (at most 192 paths in flight + 127 awaiting their resolve pass)
+constexpr int RING_SLOTS = 320; // of the ring tracer: at most 192 paths in flight + 127 awaiting their resolve pass
 
 // per-batch device state.  pid = sample_local * n_pix + pixel_local numbers the paths of a batch.
 template <class R> struct DState

@@ -295,3 +295,25 @@ def test_fast_estimator_strategies_agree_in_the_mean(root):
         # and it is not the reference's estimator (whose light sampling is 2 pi too bright in the Cornell box)
         if "cbox" in conf:
             assert oracle.Oracle(ref, seed=13).render().mean() > 1.5 * m[0].mean()
+
+
+def test_sum_order_variants_agree_on_what_is_compared_bit_for_bit(root):
+    """The restatement in the three plausible orders of Eigen's 3- and 4-term sums: first-hit face
+    ids are the same on every pixel, hit points move in their last bits only, images by far less
+    than the parity bar (profiles/r02_sum_order_report.json counts the same at 1024 x 1024)."""
+    out = {}
+    try:
+        for v in (0, 1, 2):
+            oracle.use_sum_order(v)
+            assert oracle.lib().orc_sum_order() == v
+            ref = scene_io.load_conf(os.path.join(root, "config/cbox.conf"), root_dir=root, width=96, height=96, spp=2)
+            O = oracle.Oracle(ref, seed=13)
+            ids, pts = O.first_hit(with_points=True)
+            out[v] = (ids, pts, O.render())
+    finally:
+        oracle.use_sum_order(0)
+    for v in (1, 2):
+        assert np.array_equal(out[v][0], out[0][0])
+        assert np.nanmax(np.abs(out[v][1] - out[0][1])) < 1e-13
+        assert (out[v][1] != out[0][1]).any()                       # they ARE different arithmetic
+        assert np.abs(out[v][2] - out[0][2]).max() < 1e-9 or (np.abs(out[v][2] - out[0][2]).max(axis=-1) > 1e-9).sum() <= 2
