@@ -273,6 +273,14 @@ def main():
                             % (stream_bytes * passes / max(ps["paths"], 1))}
         # counter calibrations are per scene (and only quoted at the launch size they were collected at)
         cal = pmc_calibration(args.mode, scene_name)
+        # a calibration speaks for ONE kernel: the tracer instantiation it was collected on must be
+        # the one this run launched (a changed kernel or another plan makes the committed counters stale)
+        ran = ctx.last_kernel()
+        cal_kernel = (cal or {}).get("kernel") or ((cal or {}).get("source", "").rsplit("ptx::", 1)[-1].rstrip(")") if cal else None)
+        if cal and cal_kernel != ran:
+            print("bench.py: counter calibration of %s is for %s, this run launched %s: not quoted"
+                  % (scene_name, cal_kernel, ran), file=sys.stderr)
+            cal = None
         if cal and dom == "trace" and cal.get("paths_per_launch") == paths_per_step // world // passes:
             roofline["traffic"] = cal.get("hbm_bytes_per_launch")
             roofline["traffic_source"] = cal.get("source")
@@ -312,6 +320,7 @@ def main():
                                    % (scene_name, W, H, args.spp, info.depth, info.n_tris, info.n_lights, info.n_square_lights,
                                       args.conf, ", the headline configuration" if headline else ""),
                        "intersector": "all-triangles (plane records)" if ctx.accel_info()["brute_force"] else "BVH",
+                       "tracer_kernel": ran, "state_bytes": int(ps["state_bytes"]),
                        "global_spp": spp_total, "paths_per_step": paths_per_step,
                        "sharding": ("sample ranges per rank" if args.scheme == "samples" else "interleaved row bands of 8 per rank")
                                    + " + RCCL reduce(sum) of the radiance sums to rank 0"},

@@ -131,16 +131,16 @@ template <class R> struct Context::Impl
         }
         upload(tri_pre, pre, s);
 
-        // triangle records of the BVH, intersector order: p1, p1-p2, p1-p3 (9 scalars), face id
+        // triangle records of the BVH, intersector order: the nine float coordinates, face id, two unused words
         {
-            const int stride = (sizeof(R) == 8 ? 5 : 3) * 4; // dwords
+            const int stride = TRI_REC_Q * 4; // dwords
             std::vector<uint32_t> recs(static_cast<size_t>(std::max(brute ? 0 : F, 1)) * stride, 0u);
             if (!brute)
                 for (int k = 0; k < F; k++)
                 {
                     uint32_t *o = &recs[static_cast<size_t>(k) * stride];
-                    std::memcpy(o, &pre[static_cast<size_t>(k) * 12], 9 * sizeof(R));
-                    o[9 * sizeof(R) / 4] = static_cast<uint32_t>(bvh.tri_order[k]);
+                    std::memcpy(o, &sc.verts[static_cast<size_t>(bvh.tri_order[k]) * 9], 9 * sizeof(float));
+                    o[9] = static_cast<uint32_t>(bvh.tri_order[k]);
                 }
             upload(this->bvh, recs, s);
         }

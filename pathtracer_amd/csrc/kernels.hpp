@@ -48,7 +48,7 @@ template <class R> struct DScene
     const R *tri_nrm;          // [n_tris][4] intersector order: shading normal + flag (1: use it; 0: interpolate)
     const int32_t *tri_mat;    // [n_tris] intersector order: material id (-1: none)
     const uint4 *bvh_nodes;    // [n_nodes][4] 64-byte nodes of the 4-wide BVH (child boxes quantised to 8 bits)
-    const uint4 *bvh_tris;     // [n_tris][5 (f64) or 3 (f32)] triangle records in intersector order: p1, p1-p2, p1-p3, face id
+    const uint4 *bvh_tris;     // [n_tris][3] triangle records in intersector order: the nine float coordinates, face id
     int n_nodes, id_bits;      // id_bits: bits of a stack entry that hold the record id
     int sq_light, pad3_;       // index of the first square light (-1: none)
     int stack_levels;          // traversal stack levels held in LDS; deeper levels go to `spill`
@@ -267,10 +267,10 @@ __device__ __forceinline__ unsigned long long drop_own_plane(unsigned long long 
 // ---------------------------------------------------------------------------------------------
 // 4-wide BVH.  Nodes are 64 bytes: the corner and cell size of an 8-bit grid laid over the union of
 // the child boxes, the child boxes in grid coordinates (rounded outward by the host, which checks
-// it in exact arithmetic), four child record ids.  Triangles are records of their own (the 9
-// scalars p1, p1-p2, p1-p3 of the exact test in R and the face id: 80 bytes in f64, 48 in f32).  A
+// it in exact arithmetic), four child record ids.  Triangles are records of their own (the nine
+// vertex coordinates as the floats they are and the face id: 48 bytes in either precision).  A
 // traversal step fetches ONE record and either runs four slab tests (node: four 16-byte loads per
-// lane) or the exact test (triangle: five, or three), so every step costs one memory round trip,
+// lane) or the exact test (triangle: three), so every step costs one memory round trip,
 // and as few vector-cache accesses as the data allows -- with 64 lanes at 64 different records it
 // is the number of load instructions per step, not the bytes, that the memory pipeline feels
 // (128-byte records with full-precision boxes and precomputed cofactors: 8 % slower on the 336 k
@@ -340,27 +340,21 @@ __device__ __forceinline__ void finish_tri(float *t)
     t0 = t[3] * t[7], t1 = t[6] * t[4];
     t[11] = t0 - t1;
 }
-__device__ __forceinline__ int load_tri(const uint4 *rec, double *tri)
-{
-    const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
-    tri[0] = __hiloint2double(int(q0.y), int(q0.x)), tri[1] = __hiloint2double(int(q0.w), int(q0.z));
-    tri[2] = __hiloint2double(int(q1.y), int(q1.x)), tri[3] = __hiloint2double(int(q1.w), int(q1.z));
-    tri[4] = __hiloint2double(int(q2.y), int(q2.x)), tri[5] = __hiloint2double(int(q2.w), int(q2.z));
-    tri[6] = __hiloint2double(int(q3.y), int(q3.x)), tri[7] = __hiloint2double(int(q3.w), int(q3.z));
-    tri[8] = __hiloint2double(int(q4.y), int(q4.x));
-    finish_tri(tri);
-    return int(q4.z);
-}
-__device__ __forceinline__ int load_tri(const uint4 *rec, float *tri)
+// Triangle record of the BVH: the nine vertex coordinates as the floats they are (the reference's
+// positions are float-rounded, src/geometry/cMeshLoader.cpp:138-146) and the face id -- 48 bytes,
+// three 16-byte loads, one format for both precisions.  p1 - p2 and p1 - p3 are formed here in R,
+// with the very operations the host uses for the all-triangles table.
+template <class R> __device__ __forceinline__ int load_tri(const uint4 *rec, R *tri)
 {
     const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-    tri[0] = __uint_as_float(q0.x), tri[1] = __uint_as_float(q0.y), tri[2] = __uint_as_float(q0.z), tri[3] = __uint_as_float(q0.w);
-    tri[4] = __uint_as_float(q1.x), tri[5] = __uint_as_float(q1.y), tri[6] = __uint_as_float(q1.z), tri[7] = __uint_as_float(q1.w);
-    tri[8] = __uint_as_float(q2.x);
+    const R p1x = R(__uint_as_float(q0.x)), p1y = R(__uint_as_float(q0.y)), p1z = R(__uint_as_float(q0.z));
+    tri[0] = p1x, tri[1] = p1y, tri[2] = p1z;
+    tri[3] = p1x - R(__uint_as_float(q0.w)), tri[4] = p1y - R(__uint_as_float(q1.x)), tri[5] = p1z - R(__uint_as_float(q1.y));
+    tri[6] = p1x - R(__uint_as_float(q1.z)), tri[7] = p1y - R(__uint_as_float(q1.w)), tri[8] = p1z - R(__uint_as_float(q2.x));
     finish_tri(tri);
     return int(q2.y);
 }
-template <class R> constexpr int tri_rec_q() { return sizeof(R) == 8 ? 5 : 3; } // 16-byte words of a triangle record
+constexpr int TRI_REC_Q = 3; // 16-byte words of a triangle record
 
 // The two homes of a stack level, addressed through explicit address spaces: left generic, the
 // compiler merges the two stores of a push into one flat store behind a pointer select.
@@ -384,7 +378,7 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
     {
         visits[1]++;
         R tri[12], t;
-        const int face = load_tri(S.bvh_tris + (size_t)(T.cur - S.n_nodes) * tri_rec_q<R>(), tri);
+        const int face = load_tri(S.bvh_tris + (size_t)(T.cur - S.n_nodes) * TRI_REC_Q, tri);
         if (tri_test(tri, o, d, t))
         {
             if (ANY == 1 || (ANY == 2 && T.any))

@@ -100,6 +100,7 @@ def main():
                              if e.get("SQ_ACTIVE_INST_VALU") else None,
                              "hbm_bytes_per_launch": round(e.get("hbm_read_bytes_per_launch", 0) + e.get("hbm_write_bytes_per_launch", 0)),
                              "paths_per_launch": bench["config"]["paths_per_step"] // bench["step_stats"]["passes"],
+                             "kernel": k.replace("ptx::", ""),
                              "source": "profiles/%s_pmc.json (rocprofv3 --pmc on bench.py, %s)" % (tag, k)}
     json.dump(pmc, open(os.path.join(out_dir, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
     cal_name = "calibration.json" if scene == "cbox" else "calibration_%s.json" % scene
