@@ -33,8 +33,8 @@ constexpr int RING_ADMIT = 128;     // camera rays are admitted while at most th
 // bounce are done (4 bits) and their results (bit 20 + k: test k found a blocker)
 constexpr uint32_t RING_BOUNCE = 0xFFFFu;
 constexpr int RING_TESTS_SHIFT = 16, RING_RESULT_SHIFT = 20, RING_MAX_TESTS = 12;
-constexpr int RING_BATCH = 40;      // lanes that hand over hits / take rays together (a hand-over drains the
-                                    // wave's outstanding loads; measured plateau: 32 to 48)
+// lanes that hand over hits / take rays together (DState::ring_batch, option "ring_batch"): a
+// hand-over drains the wave's outstanding loads; measured plateau: 32 to 48, default 40
 
 // bytes of one wave's two rings and of its per-slot path table
 template <class R> constexpr size_t ring_bytes() { return size_t(RING_CAP) * (12 * sizeof(R) + 4 * 7) + size_t(RING_SLOTS) * 12; }
@@ -113,6 +113,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     bool drained = false;       // the pool has no ids left (wave-uniform)
     const uint32_t n_pix = uint32_t(B.n_pix), n_cols = uint32_t(B.n_cols);
     const int depth = B.depth;
+    const int RING_BATCH = st.ring_batch;
     const V3<R> cam_pos = {R(cam.pos[0]), R(cam.pos[1]), R(cam.pos[2])};
     DoneQueue &dq = done_queues[threadIdx.x >> 6];
     uint32_t dq_head = 0, dq_count = 0;               // wave-uniform

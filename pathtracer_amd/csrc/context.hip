@@ -86,6 +86,7 @@ struct StateNeeds
     int slots = LANE_SLOTS; // record slots per wave
     size_t ring_bytes = 0; // per wave (ring tracer)
     int spill_levels = 0;  // traversal stack levels kept in global memory, per lane
+    int ring_batch = 40;   // ring tracer: lanes per hand-over
 };
 
 // State region of ptx_render_static: device memory the library owns from load to unload, one
@@ -270,6 +271,7 @@ template <class R> struct Context::Impl
         st.N = n.paths;
         st.n_waves = 0;
         st.slots = n.slots;
+        st.ring_batch = n.ring_batch;
         return total;
     }
 
@@ -924,6 +926,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
         need.slots = plan.rings ? RING_SLOTS : LANE_SLOTS;
         need.ring_bytes = plan.rings ? ring_bytes<R>() : 0;
         need.spill_levels = brute_ ? 0 : std::max(geo_->stack_need - plan.stack_levels, 0);
+        need.ring_batch = ring_batch;
         if (im.layout_state(nullptr, need, &spill) <= budget)
             break;
         // too large: first smaller batches (they cost a few per cent at most), then a smaller grid

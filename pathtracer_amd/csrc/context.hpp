@@ -100,6 +100,8 @@ public:
     // BVH scenes with at most 12 square lights: the tracer that queues hits and rays per wave (ring tracer)
     // instead of the one that keeps every path on its lane
     bool bvh_rings = true;
+    // ring tracer: lanes that hand over hits / take rays together (1..64)
+    int ring_batch = 40;
 
     struct Geometry;
     template <class R> struct Impl;

@@ -105,6 +105,7 @@ template <class R> struct DState
     int64_t N;                      // capacity (paths per batch)
     int n_waves;                    // waves of the current batch
     int slots;                      // record slots per wave (LANE_SLOTS or RING_SLOTS)
+    int ring_batch;                 // ring tracer: lanes that hand over hits / take rays together
 };
 
 // the record of (wave g, slot, bounce)

@@ -44,22 +44,30 @@ def run(conf, size, img, spp):
         same_pts = ((pts[v] == pts[0]) | (np.isnan(pts[v]) & np.isnan(pts[0]))).all(axis=1)
         diff = np.abs(ims[v] - ims[0]).max(axis=-1)
         bad = np.argwhere(diff > 1e-9)
-        # a tie on the path of one of the pixel's samples, as either order traces it
+        # a tie on the path of one of the pixel's samples, as either order traces it; otherwise:
+        # do both orders walk the same faces (then only the arithmetic along the path differs)?
         tied = np.zeros(len(bad), bool)
+        faces = {}
         for order in (0, v):
             oracle.use_sum_order(order)
             small = scene_io.load_conf(os.path.join(ROOT, conf), root_dir=ROOT, width=img, height=img, spp=spp)
             Oo = oracle.Oracle(small, seed=13)
             for k, (r, c) in enumerate(bad):
-                if any(Oo.trace_sample(int(c), int(r), s)[2].min(initial=np.inf) <= TIE_GAP for s in range(spp)):
+                tr = [Oo.trace_sample(int(c), int(r), s) for s in range(spp)]
+                faces[(order, k)] = [t[1].tolist() for t in tr]
+                if any(t[2].min(initial=np.inf) <= TIE_GAP for t in tr):
                     tied[k] = True
         ties = int(tied.sum())
+        same_path = sum(1 for k in range(len(bad)) if not tied[k] and faces[(0, k)] == faces[(v, k)])
+        untied_max = max([float(diff[r, c]) for k, (r, c) in enumerate(bad) if not tied[k]], default=0.0)
         out["order_%d_vs_0" % v] = {
             "first_hit_ids_changed": int((ids[v] != ids[0]).sum()),
             "hit_points_changed_in_some_bit": int((~same_pts).sum()),
             "largest_hit_point_change": float(np.nanmax(np.abs(pts[v] - pts[0]))) if (~same_pts).any() else 0.0,
             "image_pixels_beyond_1e-9": int(len(bad)),
             "of_which_with_a_closest_hit_tie_on_a_path": ties,
+            "of_the_rest_on_unchanged_paths": same_path,
+            "largest_change_without_a_tie": untied_max,
             "largest_image_change": float(diff.max()),
         }
     return out
