@@ -305,6 +305,18 @@ def main():
         torch.cuda.synchronize()
         other_value = W * H * args.spp / (time.perf_counter() - t1) / 1e6 if world == 1 else None
 
+        # the physically based estimator on the same frame, one step, for the record (another
+        # estimator: its paths are shorter and every light costs a visibility test; not the metric)
+        fast = None
+        if world == 1:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            fst = render_fn(out, spp=args.spp, sample_offset=0, spp_total=args.spp, mode=args.mode, seed=13, estimator="fast")
+            torch.cuda.synchronize()
+            fast = {"value": round(W * H * args.spp / (time.perf_counter() - t1) / 1e6, 3), "unit": "Mpaths/s", "dtype": args.mode,
+                    "kernel": ctx.last_kernel(), "segments_per_path": round(fst["segments"] / fst["paths"], 3),
+                    "shadow_rays_per_path": round(fst["shadow_rays"] / fst["paths"], 3)}
+
         cpu = None
         checks = None
         if not args.no_cpu_baseline and world == 1:
@@ -331,7 +343,7 @@ def main():
                                                    "bvh_nodes", "bvh_tris")},
             "other_mode": {"dtype": other_mode, "value": None if other_value is None else round(other_value, 3),
                            "wave_iterations": int(ost["wave_iterations"]), "passes": int(ost["passes"])},
-            "cpu_baseline": cpu, "checks": checks,
+            "fast_estimator": fast, "cpu_baseline": cpu, "checks": checks,
         }
     if use_dist:
         dist.barrier()

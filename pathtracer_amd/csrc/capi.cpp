@@ -3,6 +3,7 @@
 #include "context.hpp"
 #include "plane_records.hpp"
 #include "scene.hpp"
+#include "sum_order.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -66,7 +67,9 @@ int fail_arg(const char *what)
 extern "C" {
 
 const char *ptx_last_error(void) { return g_last_error.c_str(); }
-const char *ptx_version(void) { return "pathtracer_amd 0.1 (gfx950)"; }
+#define PTX_STR_(x) #x
+#define PTX_STR(x) PTX_STR_(x)
+const char *ptx_version(void) { return "pathtracer_amd 0.2 (gfx950, sum order " PTX_STR(PTX_SUM) ")"; }
 
 int ptx_scene_load_conf(const char *conf_path, const char *root_dir, const ptx_overrides *ov, ptx_scene **out)
 {

@@ -12,6 +12,8 @@
 //   lights .............. src/tracing/cLight.cpp:73-109, 188-255
 //   BxDFs ............... src/tracing/cBxDF.cpp:69-95, 156-227
 #pragma once
+#include "sum_order.hpp"
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -40,11 +42,11 @@ template <class R> __device__ __forceinline__ V3<R> cross(V3<R> a, V3<R> b)
 #pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-template <class R> __device__ __forceinline__ R norm(V3<R> a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+template <class R> __device__ __forceinline__ R norm(V3<R> a) { return sqrt(PTX_SQ4(a.x * a.x, a.y * a.y, a.z * a.z)); }
 // Eigen's normalized(): divide by the norm when the squared norm is > 0, else leave unchanged
 template <class R> __device__ __forceinline__ V3<R> normalized(V3<R> a)
 {
-    R z = a.x * a.x + a.y * a.y + a.z * a.z;
+    R z = PTX_SQ4(a.x * a.x, a.y * a.y, a.z * a.z);
     if (z > R(0))
     {
         R n = sqrt(z);
@@ -136,14 +138,14 @@ template <class R> __device__ __forceinline__ bool tri_test(const R *__restrict_
     const R c00 = by * d.z - d.y * bz;
     const R c10 = bz * d.x - d.z * bx;
     const R c20 = bx * d.y - d.x * by;
-    const R det = c00 * ax + c10 * ay + c20 * az;
+    const R det = PTX_SUM3(c00 * ax, c10 * ay, c20 * az);
     const R inv = R(1) / det;
-    const R beta = (c00 * inv) * rx + (c10 * inv) * ry + (c20 * inv) * rz;
+    const R beta = PTX_SUM3((c00 * inv) * rx, (c10 * inv) * ry, (c20 * inv) * rz);
     const R i10 = (d.y * az - ay * d.z) * inv;
     const R i11 = (d.z * ax - az * d.x) * inv;
     const R i12 = (d.x * ay - ax * d.y) * inv;
-    const R gamma = i10 * rx + i11 * ry + i12 * rz;
-    const R t = (T[9] * inv) * rx + (T[10] * inv) * ry + (T[11] * inv) * rz;
+    const R gamma = PTX_SUM3(i10 * rx, i11 * ry, i12 * rz);
+    const R t = PTX_SUM3((T[9] * inv) * rx, (T[10] * inv) * ry, (T[11] * inv) * rz);
     const R alpha = R(1) - beta - gamma;
     t_out = t;
     return (R(0) - eps < alpha) && (alpha < R(1) + eps) && (R(0) - eps < beta) && (beta < R(1) + eps) &&

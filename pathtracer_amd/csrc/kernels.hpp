@@ -642,11 +642,7 @@ template <class R> __device__ __forceinline__ void primary_ray(const DCamera &ca
 #pragma unroll
     for (int i = 0; i < 3; i++)
     {
-        double s = cam.m[i * 4 + 0] * v0;
-        s += cam.m[i * 4 + 1] * v1;
-        s += cam.m[i * 4 + 2] * 1.0;
-        s += cam.m[i * 4 + 3] * 1.0;
-        p[i] = s;
+        p[i] = PTX_SUM4(cam.m[i * 4 + 0] * v0, cam.m[i * 4 + 1] * v1, cam.m[i * 4 + 2] * 1.0, cam.m[i * 4 + 3] * 1.0);
     }
     V3<double> g = {p[0] - cam.pos[0], p[1] - cam.pos[1], p[2] - cam.pos[2]};
     V3<double> n = normalized(g);

@@ -9,6 +9,7 @@
 //   src/tracing/cPathTracer.cpp:148-182,215-259   raster->world matrix, PathTracer block
 //   src/tracing/cLight.cpp:266-358         Light block (positions and radii times WorldScale)
 #include "scene.hpp"
+#include "sum_order.hpp"
 #include "json.hpp"
 
 #include <cmath>
@@ -172,7 +173,7 @@ void invert4(const double *m, double *inv)
             m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
     a[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] +
             m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
-    double det = m[0] * a[0] + m[1] * a[4] + m[2] * a[8] + m[3] * a[12];
+    double det = PTX_SUM4(m[0] * a[0], m[1] * a[4], m[2] * a[8], m[3] * a[12]);
     double id = 1.0 / det;
     for (int i = 0; i < 16; i++)
         inv[i] = a[i] * id;
@@ -184,11 +185,8 @@ void mul4(const double *a, const double *b, double *o)
     for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++)
         {
-            double s = a[i * 4 + 0] * b[0 * 4 + j];
-            s += a[i * 4 + 1] * b[1 * 4 + j];
-            s += a[i * 4 + 2] * b[2 * 4 + j];
-            s += a[i * 4 + 3] * b[3 * 4 + j];
-            r[i * 4 + j] = s;
+            r[i * 4 + j] = PTX_SUM4(a[i * 4 + 0] * b[0 * 4 + j], a[i * 4 + 1] * b[1 * 4 + j], a[i * 4 + 2] * b[2 * 4 + j],
+                                    a[i * 4 + 3] * b[3 * 4 + j]);
         }
     std::memcpy(o, r, sizeof(r));
 }

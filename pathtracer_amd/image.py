@@ -3,7 +3,9 @@ gamma: src/tracing/cPathTracer.cpp:261-284 of the reference): statistics of one 
 two, and merging of partial radiance sums (row bands or sample ranges rendered separately).
 
 Command line:  python -m pathtracer_amd.image A.ppm [B.ppm] [--tolerance T]
-prints one JSON object; with two images the exit code is 1 when the relative MSE exceeds T.
+prints one JSON object (relative MSE -- the measure of the parity bar --, PSNR, CIE76 colour
+difference, a FLIP-like perceptual mean); with two images the exit code is 1 when the relative MSE
+exceeds T.
 """
 import json
 import sys
@@ -39,16 +41,51 @@ def image_stats(img):
             "black_pixels": int((v.reshape(-1, 3).max(1) == 0).sum())}
 
 
+def to_lab(img):
+    """CIE L*a*b* (D65) of an image whose values are LINEAR radiance in [0, 1] -- what the reference
+    writes: its PPM has no gamma.  Values above 1 are clipped."""
+    rgb = np.clip(to_linear(img), 0.0, 1.0)
+    m = np.array([[0.4124564, 0.3575761, 0.1804375], [0.2126729, 0.7151522, 0.0721750], [0.0193339, 0.1191920, 0.9503041]])
+    xyz = rgb @ m.T / np.array([0.95047, 1.0, 1.08883])
+    f = np.where(xyz > (6.0 / 29.0) ** 3, np.cbrt(xyz), xyz / (3 * (6.0 / 29.0) ** 2) + 4.0 / 29.0)
+    return np.stack([116.0 * f[..., 1] - 16.0, 500.0 * (f[..., 0] - f[..., 1]), 200.0 * (f[..., 1] - f[..., 2])], axis=-1)
+
+
+def delta_e(a, b):
+    """Per-pixel colour difference CIE76 (Euclidean distance in L*a*b*): about 2.3 is a just
+    noticeable difference."""
+    return np.sqrt(np.sum((to_lab(a) - to_lab(b)) ** 2, axis=-1))
+
+
+def flip_lite(a, b, radius=2):
+    """A perceptual error map in [0, 1] in the spirit of FLIP, much reduced: the CIE76 difference of
+    the two images after a small box blur (a stand-in for the eye's spatial filtering, so that
+    per-pixel Monte Carlo noise weighs less than structure), mapped through 1 - exp(-dE / 20).
+    No viewing-distance model, no feature term: a ranking aid, not the published metric."""
+    def blur(x):
+        x = to_linear(x)
+        k = 2 * radius + 1
+        p = np.pad(x, ((radius, radius), (radius, radius), (0, 0)), mode="edge")
+        c = np.cumsum(np.cumsum(p, axis=0), axis=1)
+        c = np.pad(c, ((1, 0), (1, 0), (0, 0)))
+        return (c[k:, k:] - c[:-k, k:] - c[k:, :-k] + c[:-k, :-k]) / (k * k)
+    return 1.0 - np.exp(-delta_e(blur(a), blur(b)) / 20.0)
+
+
 def compare(a, b):
-    """Relative MSE, PSNR over the 8-bit range, largest channel difference and where it is."""
+    """Relative MSE, PSNR over the 8-bit range, largest channel difference and where it is, the
+    CIE76 colour difference (mean, 95th percentile, largest) and the mean of the FLIP-like map."""
     la, lb = to_linear(a), to_linear(b)
     d = np.abs(la - lb)
     at = np.unravel_index(int(np.argmax(d.max(-1))), d.shape[:2])
     mse = float(np.mean((la - lb) ** 2))
+    de = delta_e(a, b)
     return {"relative_mse": relative_mse(a, b), "mse": mse,
             "psnr_db": float("inf") if mse == 0.0 else float(-10.0 * np.log10(mse)),
             "max_abs_diff": float(d.max()), "max_at_row_col": [int(at[0]), int(at[1])],
-            "differing_pixels": int((d.max(-1) > 0).sum())}
+            "differing_pixels": int((d.max(-1) > 0).sum()),
+            "delta_e76_mean": float(de.mean()), "delta_e76_p95": float(np.percentile(de, 95)), "delta_e76_max": float(de.max()),
+            "flip_lite_mean": float(flip_lite(a, b).mean())}
 
 
 def merge_partial_sums(parts):

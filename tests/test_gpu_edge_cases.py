@@ -254,3 +254,25 @@ def test_ring_tracer_with_several_square_lights(mis):
     limg, lst = lane.render(mode="f64", seed=13)
     assert np.array_equal(limg, img)
     assert (lst["segments"], lst["shadow_rays"], lst["records"]) == (st["segments"], st["shadow_rays"], st["records"])
+
+
+def test_state_that_does_not_fit_shrinks_or_fails_cleanly(cbox):
+    """The path state is sized against the memory there is: a depth whose record slots would take
+    terabytes on the full grid runs on a smaller one, a request that cannot be met at all comes back
+    as an error code, and either way the context renders the next frame as if nothing had happened."""
+    ref = copy.deepcopy(cbox)
+    c = pt.Context(0)
+    c.build_accel(gpu_scene(ref))
+    base, st0 = c.render(mode="f64", seed=13)
+    deep, st = c.render(mode="f64", seed=13, depth=65535)            # 192 slots x 65535 bounces x 64 B per wave
+    assert np.isfinite(deep).all() and st["paths"] == st0["paths"] and st["state_bytes"] > st0["state_bytes"]
+    assert st["segments"] >= st0["segments"]
+    again, st1 = c.render(mode="f64", seed=13)
+    assert np.array_equal(again, base) and st1["segments"] == st0["segments"]
+    with pytest.raises(pt.PtxError) as e:
+        c.render(mode="f64", depth=70000)
+    assert e.value.code == 1
+    huge, _ = c.render(mode="f64", seed=13, batch_paths=1 << 40)   # a batch is never larger than the frame
+    assert np.array_equal(huge, base)
+    again, _ = c.render(mode="f64", seed=13)
+    assert np.array_equal(again, base)

@@ -75,3 +75,20 @@ def test_merge_of_partial_sums_is_the_whole_frame():
     halves = [full * 0.25, full * 0.75]                     # sample ranges at the same spp_total
     assert np.allclose(image.merge_partial_sums(halves), full, rtol=0, atol=1e-15)
     assert np.array_equal(pt.finalize_image(image.merge_partial_sums(bands)), pt.finalize_image(full))
+
+
+def test_colour_difference_and_perceptual_map():
+    from pathtracer_amd import image
+    rng = np.random.default_rng(0)
+    a = rng.uniform(0, 1, (24, 32, 3))
+    assert np.allclose(image.to_lab(np.ones((1, 1, 3))), [[[100.0, 0.0, 0.0]]], atol=1e-3)      # white point
+    assert np.allclose(image.to_lab(np.zeros((1, 1, 3))), 0.0, atol=1e-9)
+    assert image.delta_e(a, a).max() == 0 and image.flip_lite(a, a).max() == 0
+    # a uniform luminance step of 1 % is far below, inverting the image far above a just noticeable difference
+    assert image.delta_e(a * 0.99, a).mean() < 1.0 < 2.3 < image.delta_e(1 - a, a).mean()
+    noisy = np.clip(a + rng.normal(0, 0.05, a.shape), 0, 1)
+    shifted = np.clip(a + 0.05, 0, 1)
+    # the blur makes zero-mean noise weigh less than a shift of the same size
+    assert image.flip_lite(noisy, a).mean() < image.flip_lite(shifted, a).mean()
+    c = image.compare((a * 255).astype(np.int64), (shifted * 255).astype(np.int64))
+    assert {"delta_e76_mean", "delta_e76_p95", "delta_e76_max", "flip_lite_mean"} <= set(c) and c["delta_e76_mean"] > 0
