@@ -309,6 +309,7 @@ def main():
         # estimator: its paths are shorter and every light costs a visibility test; not the metric)
         fast = None
         if world == 1:
+            render_fn(out, spp=1, sample_offset=0, spp_total=1, mode=args.mode, seed=13, estimator="fast")   # its kernel and state, untimed
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             fst = render_fn(out, spp=args.spp, sample_offset=0, spp_total=args.spp, mode=args.mode, seed=13, estimator="fast")

@@ -36,8 +36,12 @@ constexpr int RING_TESTS_SHIFT = 16, RING_RESULT_SHIFT = 20, RING_MAX_TESTS = 12
 // lanes that hand over hits / take rays together (DState::ring_batch, option "ring_batch"): a
 // hand-over drains the wave's outstanding loads; measured plateau: 32 to 48, default 40
 
-// bytes of one wave's two rings and of its per-slot path table
-template <class R> constexpr size_t ring_bytes() { return size_t(RING_CAP) * (12 * sizeof(R) + 4 * 7) + size_t(RING_SLOTS) * 12; }
+// bytes of one wave's two rings and of its per-slot path table (fast: the table also holds what the
+// physically based estimator carries from bounce to bounce)
+template <class R> constexpr size_t ring_bytes(bool fast = false)
+{
+    return size_t(RING_CAP) * (12 * sizeof(R) + 4 * 7) + size_t(RING_SLOTS) * (12 + (fast ? 7 * sizeof(R) : 0));
+}
 
 
 // views of the two rings of one wave (structure of arrays: one field of 256 entries after the
@@ -57,6 +61,11 @@ template <class R> struct Rings
     uint32_t *h_slot, *h_bounce; // h_bounce: state word
     // path table, by record slot
     uint32_t *s_pid, *s_klo, *s_khi;
+    // physically based estimator: throughput [3][SLOTS], the density the path's current direction
+    // was sampled with (-1: a delta lobe, -2: only delta lobes since the camera), and the origin
+    // [3][SLOTS] of its current ray -- written by the shading pass that sends the ray out, read by
+    // the one that shades its hit; the traversal in between needs none of it
+    R *s_thr, *s_pdf, *s_org;
     __device__ explicit Rings(void *base)
     {
         R *f = reinterpret_cast<R *>(base);
@@ -68,6 +77,7 @@ template <class R> struct Rings
         h_tri = reinterpret_cast<int32_t *>(u + 4 * RING_CAP);
         h_slot = u + 5 * RING_CAP, h_bounce = u + 6 * RING_CAP;
         s_pid = u + 7 * RING_CAP, s_klo = s_pid + RING_SLOTS, s_khi = s_klo + RING_SLOTS;
+        s_thr = reinterpret_cast<R *>(s_khi + RING_SLOTS), s_pdf = s_thr + 3 * RING_SLOTS, s_org = s_pdf + RING_SLOTS;
     }
 };
 
@@ -86,7 +96,12 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
 }
 
-template <class R, bool TAB, bool SQ>
+// FAST: the physically based estimator (device_math.hpp) on the same rings.  Every light needs its
+// visibility test (SQ is set), a hit goes round once per light with a valid sample as a hit of the
+// reference's estimator does per square light, every segment writes a record (light-sampling
+// term, what else the segment collected), both already multiplied by the throughput, and the
+// resolve pass is a plain sum; a path that loses the roulette simply sends no ray out.
+template <class R, bool TAB, bool SQ, bool FAST = false>
 __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCamera &cam, const DBatch &B, const DState<R> &st, int chunk)
 {
     __shared__ R lds_mats[TAB ? LDS_MATS * MAT_STRIDE : 1];
@@ -107,7 +122,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     const int g = global_wave(), lane = lane_id();
     if (g >= st.n_waves)
         return;
-    const Rings<R> Q(st.rings + size_t(g) * ring_bytes<R>());
+    const Rings<R> Q(st.rings + size_t(g) * ring_bytes<R>(FAST));
     const uint32_t n_paths = uint32_t(B.n_paths);
     uint32_t next = 0, end = 0; // the wave's current range of path ids
     bool drained = false;       // the pool has no ids left (wave-uniform)
@@ -178,6 +193,11 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 const int i = top - k;
                 if (i >= 0 && i < len)
                 {
+                    if constexpr (FAST)
+                    {
+                        fr += q[k][0] + q[k][3], fg += q[k][1] + q[k][4], fb += q[k][2] + q[k][5];
+                        continue;
+                    }
                     fr = q[k][0] + q[k][3] * fr;
                     fg = q[k][1] + q[k][4] * fg;
                     fb = q[k][2] + q[k][5] * fb;
@@ -249,7 +269,156 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 m = lds_mats + mrow;
             else
                 m = S.mats + mrow;
-            if (mat_id < 0)
+            if constexpr (FAST)
+            {
+                // what the path carries: throughput, the density of its current direction, its ray's origin
+                V3<R> thr = {R(1), R(1), R(1)};
+                R pdf_prev = R(-2);
+                V3<R> other = {R(0), R(0), R(0)};
+                if (bnc > 0)
+                {
+                    thr = {Q.s_thr[s_slot], Q.s_thr[RING_SLOTS + s_slot], Q.s_thr[2 * RING_SLOTS + s_slot]};
+                    pdf_prev = Q.s_pdf[s_slot];
+                }
+                // conf lights the ray crossed before its hit: emitters that do not occlude
+                if (pdf_prev > R(-2))
+                {
+                    const V3<R> org = {Q.s_org[s_slot], Q.s_org[RING_SLOTS + s_slot], Q.s_org[2 * RING_SLOTS + s_slot]};
+                    const R t_geom = hit_k >= 0 ? norm(p - org) : Consts<R>::big;
+                    for (int l = 0; l < S.n_lights; l++)
+                    {
+                        const R *L;
+                        if constexpr (TAB)
+                            L = lds_lights + l * LIGHT_STRIDE;
+                        else
+                            L = S.lights + (size_t)l * LIGHT_STRIDE;
+                        R tl;
+                        const R pl = fast_light_pdf(L, org, sd, tl);
+                        if (pl > R(0) && tl < t_geom)
+                        {
+                            const R w = pdf_prev < R(0) ? R(1) : pdf_prev / (pdf_prev + pl);
+                            other = other + V3<R>{thr.x * L[1] * w, thr.y * L[2] * w, thr.z * L[3] * w};
+                        }
+                    }
+                }
+                if (mat_id < 0 || m[13] != R(0))
+                {
+                    if (mat_id >= 0 && pdf_prev == R(-2))
+                        other = other + V3<R>{thr.x * m[0], thr.y * m[1], thr.z * m[2]}; // an emitter the camera sees
+                    store_record(record_at(st, g, s_slot, depth, uint32_t(bnc)), V3<R>{R(0), R(0), R(0)}, other);
+                    n_rec++;
+                    finished = true, fin_state = uint32_t(bnc + 1) << 16;
+                }
+                else
+                {
+                    const V3<R> wo = -sd;
+                    const R *__restrict__ fn = S.tri_nrm + (size_t)hit_k * 4;
+                    const R fn0 = fn[0], fn1 = fn[1], fn2 = fn[2], fn3 = fn[3];
+                    V3<R> nrm = {fn0, fn1, fn2};
+                    if (fn3 == R(0))
+                    {
+                        const int face = S.tri_face[hit_k];
+                        const Float9 fv = load9(S.verts + (size_t)face * 9), fq = load9(S.normals + (size_t)face * 9);
+                        V3<R> a = {R(fv.v[0]), R(fv.v[1]), R(fv.v[2])}, b = {R(fv.v[3]), R(fv.v[4]), R(fv.v[5])}, c = {R(fv.v[6]), R(fv.v[7]), R(fv.v[8])};
+                        V3<R> w = barycentric(p, a, b, c);
+                        V3<R> acc = w.x * V3<R>{R(fq.v[0]), R(fq.v[1]), R(fq.v[2])};
+                        acc = acc + w.y * V3<R>{R(fq.v[3]), R(fq.v[4]), R(fq.v[5])};
+                        acc = acc + w.z * V3<R>{R(fq.v[6]), R(fq.v[7]), R(fq.v[8])};
+                        nrm = fast_normalized(acc);
+                    }
+                    const int D0 = 4 * S.n_lights;
+                    V3<R> direct = {R(0), R(0), R(0)};
+                    bool go_on = S.enable_indirect != 0;
+                    R pdf_next = pdf_prev;
+                    if (m[12] != R(0))
+                    {
+                        if (go_on)
+                        {
+                            wi = fast_glass_sample(m, nrm, wo, rng_draw<R>(key, sample, bnc, D0));
+                            pdf_next = pdf_prev == R(-2) ? R(-2) : R(-1);
+                        }
+                    }
+                    else
+                    {
+                        if (dot(nrm, wo) < R(0))
+                            nrm = -nrm;
+                        int k_test = 0; // lights with a valid sample met so far
+                        for (int l = 0; l < S.n_lights; l++)
+                        {
+                            const R *L;
+                            if constexpr (TAB)
+                                L = lds_lights + l * LIGHT_STRIDE;
+                            else
+                                L = S.lights + (size_t)l * LIGHT_STRIDE;
+                            const R x1 = rng_draw<R>(key, sample, bnc, 4 * l + 0);
+                            const R x2 = rng_draw<R>(key, sample, bnc, 4 * l + 1);
+                            V3<R> wl, q;
+                            const R pl = fast_light_sample(L, p, x1, x2, wl, q);
+                            if (!(pl > R(0)))
+                                continue;
+                            R pb;
+                            const V3<R> f = fast_brdf(m, nrm, wo, wl, pb);
+                            const R cn = dot(nrm, wl);
+                            if (!(cn > R(0)))
+                                continue;
+                            if (k_test == tested)
+                            {
+                                defer = true, defer_light = l, defer_state = state; // the next test this bounce needs
+                                break;
+                            }
+                            const bool blocked = ((state >> (RING_RESULT_SHIFT + k_test)) & 1u) != 0u;
+                            k_test++;
+                            if (blocked)
+                                continue;
+                            const R w = (go_on && bnc + 1 < depth) ? cn / (pl + pb) : cn / pl;
+                            direct = direct + V3<R>{thr.x * L[1] * f.x * w, thr.y * L[2] * f.y * w, thr.z * L[3] * f.z * w};
+                        }
+                        if (!defer && go_on)
+                        {
+                            const R x0 = rng_draw<R>(key, sample, bnc, D0), x1 = rng_draw<R>(key, sample, bnc, D0 + 1);
+                            const R x2 = rng_draw<R>(key, sample, bnc, D0 + 2);
+                            go_on = fast_brdf_sample(m, nrm, wo, x0, x1, x2, wi);
+                            if (go_on)
+                            {
+                                R pb;
+                                const V3<R> f = fast_brdf(m, nrm, wo, wi, pb);
+                                go_on = pb > R(0);
+                                if (go_on)
+                                {
+                                    const R c = dot(nrm, wi) / pb;
+                                    thr = {thr.x * (f.x * c), thr.y * (f.y * c), thr.z * (f.z * c)};
+                                    pdf_next = pb;
+                                }
+                            }
+                        }
+                    }
+                    if (!defer)
+                    {
+                        store_record(record_at(st, g, s_slot, depth, uint32_t(bnc)), direct, other);
+                        n_rec++;
+                        if (go_on && bnc >= 3)
+                        {
+                            // Russian roulette
+                            const R q = fmin(max3(thr.x, thr.y, thr.z), R(0.95));
+                            go_on = rng_draw<R>(key, sample, bnc, D0 + 3) < q;
+                            if (go_on)
+                                thr = {thr.x / q, thr.y / q, thr.z / q};
+                        }
+                        if (go_on && bnc + 1 < depth)
+                        {
+                            cont = true;
+                            Q.s_thr[s_slot] = thr.x, Q.s_thr[RING_SLOTS + s_slot] = thr.y, Q.s_thr[2 * RING_SLOTS + s_slot] = thr.z;
+                            Q.s_pdf[s_slot] = pdf_next;
+                            Q.s_org[s_slot] = p.x, Q.s_org[RING_SLOTS + s_slot] = p.y, Q.s_org[2 * RING_SLOTS + s_slot] = p.z;
+                        }
+                        else
+                            finished = true, fin_state = uint32_t(bnc + 1) << 16;
+                    }
+                    else
+                        n_tests++;
+                }
+            }
+            else if (mat_id < 0)
                 finished = true, fin_state = uint32_t(bnc) << 16;
             else if (m[13] != R(0))
                 finished = true, fin_state = (uint32_t(bnc) << 16) | uint32_t(mat_id + 1);
@@ -485,7 +654,14 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                     const uint32_t sample = uint32_t(B.sample0) + Q.s_pid[slot] / n_pix;
                     const R x1 = rng_draw<R>(key, sample, bounce & RING_BOUNCE, 4 * test_light + 0);
                     const R x2 = rng_draw<R>(key, sample, bounce & RING_BOUNCE, 4 * test_light + 1);
-                    const V3<R> s = square_light_point(L, x1, x2);
+                    V3<R> s;
+                    if constexpr (FAST)
+                    {
+                        V3<R> unused;
+                        (void)fast_light_sample(L, vp, x1, x2, unused, s); // the same point the shading pass computed
+                    }
+                    else
+                        s = square_light_point(L, x1, x2);
                     const R dist = norm(s - vp);
                     o = s, d = normalized(vp - s);
                     trav_init(T, o, d, dist);
@@ -521,6 +697,16 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     }
 }
 
+template <bool TAB>
+__global__ void __launch_bounds__(BLOCK, 2) k_trace_rings_fast_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
+{
+    trace_body_rings<double, TAB, true, true>(S, cam, B, st, chunk);
+}
+template <bool TAB>
+__global__ void __launch_bounds__(BLOCK, 3) k_trace_rings_fast_f32(DScene<float> S, DCamera cam, DBatch B, DState<float> st, int chunk)
+{
+    trace_body_rings<float, TAB, true, true>(S, cam, B, st, chunk);
+}
 template <bool TAB, bool SQ>
 __global__ void __launch_bounds__(BLOCK, 3) k_trace_rings_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
 {

@@ -666,8 +666,8 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
     // The reference's estimator tests square lights only, the physically based one every light.
     const int n_tested = fast ? S.n_lights : S.n_square;
     const int lights = n_tested == 0 ? 0 : ((BRUTE && S.n_lights == 1 && shadow_queue) ? 1 : 2);
-    if (fast)
-        rings = false; // the physically based estimator runs on the lane tracer
+    if (fast && S.n_lights > RING_MAX_TESTS)
+        rings = false; // the state word of a ring entry counts up to 12 visibility tests per bounce
     auto pick = [&](auto tab_c) {
         constexpr bool TAB = decltype(tab_c)::value;
         if (fast)
@@ -712,7 +712,18 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
                       tab ? "true" : "false", (fast && lights != 1) ? 2 : lights);
         p.name = nm;
     }
-    if (!BRUTE && S.n_square <= 12 && rings)
+    if (!BRUTE && fast && rings)
+    {
+        p.rings = true;
+        if constexpr (sizeof(R) == 8)
+            p.kernel = tab ? k_trace_rings_fast_f64<true> : k_trace_rings_fast_f64<false>;
+        else
+            p.kernel = tab ? k_trace_rings_fast_f32<true> : k_trace_rings_fast_f32<false>;
+        char nm[96];
+        std::snprintf(nm, sizeof(nm), "k_trace_rings_fast_%s<%s>", sizeof(R) == 8 ? "f64" : "f32", tab ? "true" : "false");
+        p.name = nm;
+    }
+    else if (!BRUTE && S.n_square <= 12 && rings)
     {
         // the tracer that keeps more paths in flight than lanes (its state word counts up to 12
         // visibility tests per bounce)
@@ -924,7 +935,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
         need.paths = cap, need.depth = depth;
         need.waves = grid_blocks * (BLOCK / 64);
         need.slots = plan.rings ? RING_SLOTS : LANE_SLOTS;
-        need.ring_bytes = plan.rings ? ring_bytes<R>() : 0;
+        need.ring_bytes = plan.rings ? ring_bytes<R>(fast) : 0;
         need.spill_levels = brute_ ? 0 : std::max(geo_->stack_need - plan.stack_levels, 0);
         need.ring_batch = ring_batch;
         if (im.layout_state(nullptr, need, &spill) <= budget)

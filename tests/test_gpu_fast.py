@@ -20,18 +20,23 @@ pytestmark = pytest.mark.gpu
     ("config/cbox.conf", 48, 48, 6, dict(brute_force_limit=0)),  # through the BVH
     ("config/cbox_glossy.conf", 48, 48, 8, {}),                # Phong lobe Ns = 98
     ("config/cbox_cube.conf", 48, 48, 8, {}),
-    ("config/mis.conf", 96, 64, 4, {}),                        # five sphere lights, each with its visibility test
-    ("config/room.conf", 96, 64, 2, {})])
+    ("config/mis.conf", 96, 64, 4, {}),                        # five sphere lights, each with its visibility test: ring tracer
+    ("config/mis.conf", 96, 64, 4, dict(bvh_rings=0)),         # the same on the lane tracer
+    ("config/room.conf", 96, 64, 2, {}),
+    ("config/room.conf", 64, 48, 2, dict(bvh_rings=0))])
 def test_fast_estimator_f64_matches_oracle(root, conf, w, h, spp, kw):
     s, ref = load(root, conf, width=w, height=h, spp=spp)
     c = pt.Context(0, brute_force_limit=kw.get("brute_force_limit"))
-    if "shadow_queue" in kw:
-        c.set_option("shadow_queue", kw["shadow_queue"])
+    for k in ("shadow_queue", "bvh_rings"):
+        if k in kw:
+            c.set_option(k, kw[k])
     c.build_accel(s)
     O = oracle.Oracle(ref, seed=13, estimator="fast")
     img, st = c.render(mode="f64", seed=13, estimator="fast")
     oimg, ost = O.render(stats=True)
-    assert c.last_kernel().startswith("k_trace_fast_f64")
+    assert "fast_f64" in c.last_kernel()
+    if not c.accel_info()["brute_force"]:
+        assert ("rings" in c.last_kernel()) == bool(kw.get("bvh_rings", 1))
     assert st["paths"] == w * h * spp and st["shadow_rays"] > 0
     # relative bar: radiances reach 140 on mis (no clamp in this estimator)
     scale = np.maximum(1.0, np.abs(oimg).max(axis=-1, keepdims=True))
@@ -51,6 +56,30 @@ def test_fast_and_reference_estimators_differ(root):
     assert oracle.rmse_rel(a, b) > 20 * noise
     assert sb["segments"] < sa["segments"]                      # roulette and emitter rules shorten the paths
     assert b.mean() < a.mean()
+
+
+def test_fast_estimator_ring_tracer_equals_lane_tracer(root):
+    """BVH scenes: the ring tracer and the lane tracer run the physically based estimator on the
+    same paths -- the same numbers of segments, records and visibility tests -- to the parity bar.
+    (Not to the bit: the shading helpers allow fused multiply-adds, the compiler takes that licence
+    differently in the two kernels, and a Phong exponent of 10 000 turns an ulp into 1e-11.)"""
+    for conf, kw in (("config/mis.conf", dict(width=160, height=96, spp=6)), ("config/cbox.conf", dict(width=64, height=64, spp=4))):
+        s, _ = load(root, conf, **kw)
+        out = {}
+        for rings in (0, 1):
+            c = pt.Context(0, brute_force_limit=0)
+            c.set_option("bvh_rings", rings)
+            c.build_accel(s)
+            for mode in ("f64", "f32"):
+                img, st = c.render(mode=mode, estimator="fast")
+                assert ("rings" in c.last_kernel()) == bool(rings)
+                if mode in out:
+                    tol = 1e-9 if mode == "f64" else 1e-3
+                    assert np.abs(img - out[mode][0]).max() <= tol * max(1.0, float(np.abs(img).max())), (conf, mode)
+                    for k in ("segments", "records", "shadow_rays", "paths"):
+                        assert st[k] == out[mode][1][k], (k, conf, mode)
+                else:
+                    out[mode] = (img, st)
 
 
 def test_fast_estimator_f32_and_cuts(root):
