@@ -94,7 +94,8 @@ def main():
         modes = {"f32": ("_f32", modes["f64"][1]), "f64": ("_f64", modes["f32"][1])}
     for mode, (kname, iters_per_launch) in modes.items():
         for k, e in pmc.items():
-            if "k_trace" in k and kname in k and "SQ_INSTS_VALU" in e:
+            # the reference estimator's tracer (bench.py also runs the physically based one once, for the record)
+            if "k_trace" in k and "fast" not in k and kname in k and "SQ_INSTS_VALU" in e:
                 cal[mode] = {"valu_insts_per_wave_iteration": round(e["SQ_INSTS_VALU"] / e["launches"] / iters_per_launch, 1),
                              "active_lanes_per_valu_inst": round(e["SQ_THREAD_CYCLES_VALU"] / e["SQ_ACTIVE_INST_VALU"] / 64.0, 4)
                              if e.get("SQ_ACTIVE_INST_VALU") else None,
