@@ -101,6 +101,22 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask)
 // reference's estimator does per square light, every segment writes a record (light-sampling
 // term, what else the segment collected), both already multiplied by the throughput, and the
 // resolve pass is a plain sum; a path that loses the roulette simply sends no ray out.
+// Diagnostic build (make EXTRA=-DPTX_PHASE_TIMING): every wave adds up the shader cycles it spends
+// in each part of its loop, and a few waves print their totals when they finish.
+#ifdef PTX_PHASE_TIMING
+#define PTX_PHASE_END(k)                                                   \
+    do                                                                     \
+    {                                                                      \
+        const unsigned long long now_ = __builtin_readcyclecounter();      \
+        ph_t[k] += now_ - ph_last, ph_n[k]++;                              \
+        ph_last = now_;                                                    \
+    } while (0)
+#else
+#define PTX_PHASE_END(k) \
+    do                   \
+    {                    \
+    } while (0)
+#endif
 template <class R, bool TAB, bool SQ, bool FAST = false>
 __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCamera &cam, const DBatch &B, const DState<R> &st, int chunk)
 {
@@ -150,10 +166,15 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     int vtri = -1;
     uint32_t n_seg = 0, n_iter = 0, n_rec = 0, n_tests = 0;
     uint32_t n_visit[2] = {0, 0};
+#ifdef PTX_PHASE_TIMING
+    unsigned long long ph_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last = __builtin_readcyclecounter();
+    uint32_t ph_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     // folds 64 (or the last n) finished paths back to front, one per lane
     auto resolve = [&](uint32_t n) {
 #pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
+        PTX_PHASE_END(3);
         ring_sync(); // the records were stored by other lanes of this wave
         const uint32_t e = (dq_head + uint32_t(lane)) % DoneQueue::CAP;
         const bool mine = uint32_t(lane) < n;
@@ -228,10 +249,12 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        PTX_PHASE_END(4);
     };
 
     // shades the first n (<= 64) hits of the hit ring, one per lane
     auto shade = [&](uint32_t n) {
+        PTX_PHASE_END(7);
         ring_sync();
         n_iter++;
         const uint32_t e = (hq_head + uint32_t(lane)) % RING_CAP;
@@ -535,6 +558,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             if (dq_count >= 64u)
                 resolve(64u);
         }
+        PTX_PHASE_END(3);
     };
 
     for (;;)
@@ -557,10 +581,16 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             {
                 if (at_tri)
                     done = !bvh_step<R, SQ ? 2 : 0, 2>(S, o, d, T, stk, n_visit);
+                PTX_PHASE_END(1);
             }
-            else if (act && !at_tri)
-                done = !bvh_step<R, SQ ? 2 : 0, 1>(S, o, d, T, stk, n_visit);
+            else
+            {
+                if (act && !at_tri)
+                    done = !bvh_step<R, SQ ? 2 : 0, 1>(S, o, d, T, stk, n_visit);
+                PTX_PHASE_END(0);
+            }
         }
+        PTX_PHASE_END(7);
         // ---- completed traversals -> hit ring -----------------------------------------------------
         if (n_done >= RING_BATCH || (n_done > 0 && n_busy == n_done))
         {
@@ -584,6 +614,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             hq_count += uint32_t(__popcll(gm));
             n_busy -= __popcll(gm);
         }
+        PTX_PHASE_END(2);
         // ---- 64 hits wait: shade them (fewer only when nothing else is left to do) -----------------
         if (hq_count >= 64u)
             shade(64u);
@@ -626,6 +657,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             next += cnt;
             rq_count += cnt;
         }
+        PTX_PHASE_END(5);
         // ---- free lanes take rays --------------------------------------------------------------------
         if (rq_count > 0u && (64 - n_busy >= RING_BATCH || n_busy == 0 || __popcll(__ballot(busy && !done)) == 0))
         {
@@ -676,11 +708,18 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             rq_count -= taken;
             n_busy += int(taken);
         }
+        PTX_PHASE_END(6);
         if (n_busy == 0 && rq_count == 0u && hq_count == 0u && drained)
             break;
     }
     while (dq_count > 0u)
         resolve(dq_count < 64u ? dq_count : 64u);
+#ifdef PTX_PHASE_TIMING
+    PTX_PHASE_END(7);
+    if (lane == 0 && g % 500 == 3)
+        printf("wave %d cycles: node %llu (%u) tri %llu (%u) handover %llu (%u) shade %llu (%u) resolve %llu (%u) admit %llu (%u) take %llu (%u) other %llu (%u)\n", g,
+               ph_t[0], ph_n[0], ph_t[1], ph_n[1], ph_t[2], ph_n[2], ph_t[3], ph_n[3], ph_t[4], ph_n[4], ph_t[5], ph_n[5], ph_t[6], ph_n[6], ph_t[7], ph_n[7]);
+#endif
     // per-wave statistics (the wave owns its row)
     unsigned long long tot[5] = {n_seg, n_rec, n_visit[0], n_visit[1], n_tests};
     for (int off = 32; off > 0; off >>= 1)
@@ -697,6 +736,10 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     }
 }
 
+// workgroups per CU the reference-estimator f64 ring kernel is compiled for (168 registers at 3)
+#ifndef PTX_RINGS_F64_BLOCKS
+#define PTX_RINGS_F64_BLOCKS 3
+#endif
 template <bool TAB>
 __global__ void __launch_bounds__(BLOCK, 2) k_trace_rings_fast_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
 {
@@ -708,7 +751,7 @@ __global__ void __launch_bounds__(BLOCK, 3) k_trace_rings_fast_f32(DScene<float>
     trace_body_rings<float, TAB, true, true>(S, cam, B, st, chunk);
 }
 template <bool TAB, bool SQ>
-__global__ void __launch_bounds__(BLOCK, 3) k_trace_rings_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
+__global__ void __launch_bounds__(BLOCK, PTX_RINGS_F64_BLOCKS) k_trace_rings_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
 {
     trace_body_rings<double, TAB, SQ>(S, cam, B, st, chunk);
 }
