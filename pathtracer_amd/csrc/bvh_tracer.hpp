@@ -101,22 +101,6 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask)
 // reference's estimator does per square light, every segment writes a record (light-sampling
 // term, what else the segment collected), both already multiplied by the throughput, and the
 // resolve pass is a plain sum; a path that loses the roulette simply sends no ray out.
-// Diagnostic build (make EXTRA=-DPTX_PHASE_TIMING): every wave adds up the shader cycles it spends
-// in each part of its loop, and a few waves print their totals when they finish.
-#ifdef PTX_PHASE_TIMING
-#define PTX_PHASE_END(k)                                                   \
-    do                                                                     \
-    {                                                                      \
-        const unsigned long long now_ = __builtin_readcyclecounter();      \
-        ph_t[k] += now_ - ph_last, ph_n[k]++;                              \
-        ph_last = now_;                                                    \
-    } while (0)
-#else
-#define PTX_PHASE_END(k) \
-    do                   \
-    {                    \
-    } while (0)
-#endif
 template <class R, bool TAB, bool SQ, bool FAST = false>
 __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCamera &cam, const DBatch &B, const DState<R> &st, int chunk)
 {

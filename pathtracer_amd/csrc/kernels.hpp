@@ -814,6 +814,22 @@ struct DoneQueue
 // its ray crossed, an emitter the camera sees), both already multiplied by the throughput, every
 // segment writes one, a blocked visibility test still only zeroes the first half, and the
 // resolve pass is a plain sum.  Every light needs its visibility test here, sphere lights too.
+// Diagnostic build (make PHASE=1): every wave adds up the shader cycles it spends
+// in each part of its loop (tracers of kernels.hpp and bvh_tracer.hpp), and a few waves print their totals when they finish.
+#ifdef PTX_PHASE_TIMING
+#define PTX_PHASE_END(k)                                                   \
+    do                                                                     \
+    {                                                                      \
+        const unsigned long long now_ = __builtin_readcyclecounter();      \
+        ph_t[k] += now_ - ph_last, ph_n[k]++;                              \
+        ph_last = now_;                                                    \
+    } while (0)
+#else
+#define PTX_PHASE_END(k) \
+    do                   \
+    {                    \
+    } while (0)
+#endif
 template <class R, bool BRUTE, bool TAB, int LIGHTS, bool FAST = false>
 __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &cam, const DBatch &B, const DState<R> &st, int chunk)
 {
@@ -886,7 +902,12 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
 
     // tests the first n (<= 64) parked segments, one per lane, and removes the direct light of
     // the blocked ones from their bounce records
+#ifdef PTX_PHASE_TIMING
+    unsigned long long ph_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last = __builtin_readcyclecounter();
+    uint32_t ph_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     auto drain = [&](uint32_t n) {
+        PTX_PHASE_END(2);
         if constexpr (SQ1)
         {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -934,6 +955,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             sq_count -= n;
             sq_drained += n;
         }
+        PTX_PHASE_END(3);
     };
 
     // folds the bounce records of the first n (<= 64) finished paths back to front with the
@@ -941,6 +963,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
     // results.  The records were written by this wave a few iterations ago, so they come from L2.
     auto resolve = [&](uint32_t n) {
 #pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
+        PTX_PHASE_END(5);
         // a parked visibility test may still have to zero the direct light of one of these paths
         if constexpr (SQ1)
         {
@@ -1031,6 +1054,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        PTX_PHASE_END(4);
     };
 
     for (;;)
@@ -1127,6 +1151,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         if (__ballot(alive) == 0ull)
             break; // pool used up and every lane idle
         n_iter++;
+        PTX_PHASE_END(0);
 
         // ---- closest hit and the termination rules (miss / no material -> tail 0; emitter -> Ka) --
         bool shaded = false, finished = false; // finished: this lane's path ended in this iteration
@@ -1196,6 +1221,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 shaded = true;
         }
 
+        PTX_PHASE_END(1);
         bool park = false; // this lane has a visibility test for the queue
         R park_x1 = R(0), park_x2 = R(0);
         const uint32_t seg_pid = pid, seg_bounce = uint32_t(bounce), seg_slot = slot;
@@ -1405,6 +1431,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 finished = true, fin_state = uint32_t(bounce + 1) << 16;
         }
 
+        PTX_PHASE_END(2);
         if constexpr (SQ1)
         {
             // all lanes are back together here: park this bounce's tests, test 64 once they are there
@@ -1439,9 +1466,15 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                     resolve(64u);
             }
         }
+        PTX_PHASE_END(5);
     }
     while (dq_count > 0u)
         resolve(dq_count < 64u ? dq_count : 64u);
+#ifdef PTX_PHASE_TIMING
+    if (lane == 0 && g % 500 == 3)
+        printf("wave %d cycles: start %llu (%u) hit %llu (%u) shade %llu (%u) tests %llu (%u) resolve %llu (%u) queues %llu (%u)\n", g, ph_t[0], ph_n[0],
+               ph_t[1], ph_n[1], ph_t[2], ph_n[2], ph_t[3], ph_n[3], ph_t[4], ph_n[4], ph_t[5], ph_n[5]);
+#endif
     // per-wave statistics (the wave owns its row)
     for (int off = 32; off > 0; off >>= 1)
     {

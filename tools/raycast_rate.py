@@ -1,0 +1,46 @@
+"""Closest-hit rate of the raycast operator on incoherent rays: rays leave the first-hit points of the
+frame in random directions of the hemisphere that faces the camera (what the second segments of the
+paths look like).  Run under `rocprofv3 --kernel-trace --stats` to read the kernel's own duration; the
+wall time printed here includes the copies of the host arrays the operator takes.
+
+    python tools/raycast_rate.py config/room.conf [--rays 4194304]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pathtracer_amd as pt  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("conf")
+    ap.add_argument("--rays", type=int, default=1 << 22)
+    a = ap.parse_args()
+    s = pt.Scene.load_conf(os.path.join(ROOT, a.conf), root_dir=ROOT, width=1024, height=1024, spp=1)
+    c = pt.Context(0)
+    c.build_accel(s)
+    ids, pts = c.first_hit(with_points=True)
+    pts = pts.reshape(-1, 3)[ids.reshape(-1) >= 0]
+    rng = np.random.default_rng(13)
+    pick = rng.integers(0, len(pts), a.rays)
+    o = pts[pick]
+    cam = np.asarray(s.camera()[1], dtype=np.float64)[:3]
+    d = rng.normal(size=(a.rays, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    flip = np.einsum("ij,ij->i", d, cam - o) < 0
+    d[flip] *= -1
+    for rep in range(3):
+        t0 = time.time()
+        hit, _ = c.raycast(o, d)
+        dt = time.time() - t0
+        print("%d rays, %.1f ms wall (with copies), %.0f%% hit" % (a.rays, dt * 1e3, 100.0 * (hit >= 0).mean()), flush=True)
+
+
+if __name__ == "__main__":
+    main()
