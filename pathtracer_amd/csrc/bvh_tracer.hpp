@@ -15,19 +15,24 @@
 // (256 entries) can overflow, and the wave ends when the pool is used up and all three are empty.
 //
 // SQ (the scene has square lights, at most 12): a bounce needs the reference's visibility test for
-// every square light whose sample is valid before its record can be written.  The shading pass then does not
-// finish the hit: it sends it back through the ray ring as a SHADOW entry (same fields as a hit);
-// the lane that takes it recomputes the light sample point from the path's random numbers, runs
-// the any-hit traversal from the light to the shaded point, and hands the hit back to the hit ring
-// with the result added to its state word; the next shading pass sends it out for the next test or
-// finishes it.  The path is still in exactly one place at any time, and no record is ever patched
-// after the fact.
+// every square light whose sample is valid before its record can be written.  Shading a fresh hit
+// then only finds out which lights those are and sends one ray-ring entry per test -- the hit
+// (point, incoming direction, triangle), the light, which of the hit's tests it is and how many the
+// hit has; the ray ring is four times longer for that, and a shading pass waits until it has room
+// for the most its 64 hits can send.  The lane that takes an entry recomputes the light sample
+// point from the path's random numbers and runs the any-hit traversal from the light to the shaded
+// point, so the tests of one hit run on as many lanes at once.  A finished test adds its result to
+// the hit's word in LDS (per wave and record slot: tests done, blocker bits); the test that
+// completes the count hands the hit back to the hit ring with all results in its state word, and
+// the next shading pass finishes it: a hit is shaded twice whatever its number of tests, and no
+// record is ever patched after the fact.
 #pragma once
 
 namespace ptx
 {
 
-constexpr int RING_CAP = 256;       // entries of either ring
+constexpr int RING_CAP = 256;       // entries of the hit ring, and of the ray ring when no light needs visibility tests
+constexpr int RING_CAP_TESTS = 1024; // entries of the ray ring when hits send out visibility tests (up to 12 each)
 constexpr int RING_ADMIT = 128;     // camera rays are admitted while at most this many paths are in flight
 // state word of a ring entry: bounce in the low 16 bits, then how many visibility tests of this
 // bounce are done (4 bits) and their results (bit 20 + k: test k found a blocker)
@@ -38,9 +43,10 @@ constexpr int RING_TESTS_SHIFT = 16, RING_RESULT_SHIFT = 20, RING_MAX_TESTS = 12
 
 // bytes of one wave's two rings and of its per-slot path table (fast: the table also holds what the
 // physically based estimator carries from bounce to bounce)
-template <class R> constexpr size_t ring_bytes(bool fast = false)
+template <class R> constexpr size_t ring_bytes(bool fast = false, bool tests = false)
 {
-    return size_t(RING_CAP) * (12 * sizeof(R) + 4 * 7) + size_t(RING_SLOTS) * (12 + (fast ? 7 * sizeof(R) : 0));
+    return size_t(tests ? RING_CAP_TESTS : RING_CAP) * (6 * sizeof(R) + 4 * 4) + size_t(RING_CAP) * (6 * sizeof(R) + 4 * 3) +
+           size_t(RING_SLOTS) * (12 + (fast ? 7 * sizeof(R) : 0));
 }
 
 
@@ -48,7 +54,7 @@ template <class R> constexpr size_t ring_bytes(bool fast = false)
 // other) and of its path table.  What a path is -- its id and the key of its random numbers --
 // stays in the table, indexed by the record slot the path holds; ring entries and lanes carry the
 // slot and the state word only (registers are what the traversal loop is short of).
-template <class R> struct Rings
+template <class R, int RQ> struct Rings
 {
     // ray ring
     R *ro, *rd;        // [3][CAP] each
@@ -69,14 +75,15 @@ template <class R> struct Rings
     __device__ explicit Rings(void *base)
     {
         R *f = reinterpret_cast<R *>(base);
-        ro = f, rd = f + 3 * RING_CAP, hp = f + 6 * RING_CAP, hd = f + 9 * RING_CAP;
-        uint32_t *u = reinterpret_cast<uint32_t *>(f + 12 * RING_CAP);
-        r_slot = u, r_bounce = u + RING_CAP;
-        r_tri = reinterpret_cast<int32_t *>(u + 2 * RING_CAP);
-        r_light = reinterpret_cast<int32_t *>(u + 3 * RING_CAP);
-        h_tri = reinterpret_cast<int32_t *>(u + 4 * RING_CAP);
-        h_slot = u + 5 * RING_CAP, h_bounce = u + 6 * RING_CAP;
-        s_pid = u + 7 * RING_CAP, s_klo = s_pid + RING_SLOTS, s_khi = s_klo + RING_SLOTS;
+        ro = f, rd = f + 3 * RQ, hp = f + 6 * RQ, hd = hp + 3 * RING_CAP;
+        uint32_t *u = reinterpret_cast<uint32_t *>(hd + 3 * RING_CAP);
+        r_slot = u, r_bounce = u + RQ;
+        r_tri = reinterpret_cast<int32_t *>(u + 2 * RQ);
+        r_light = reinterpret_cast<int32_t *>(u + 3 * RQ);
+        u += 4 * RQ;
+        h_tri = reinterpret_cast<int32_t *>(u);
+        h_slot = u + RING_CAP, h_bounce = u + 2 * RING_CAP;
+        s_pid = u + 3 * RING_CAP, s_klo = s_pid + RING_SLOTS, s_khi = s_klo + RING_SLOTS;
         s_thr = reinterpret_cast<R *>(s_khi + RING_SLOTS), s_pdf = s_thr + 3 * RING_SLOTS, s_org = s_pdf + RING_SLOTS;
     }
 };
@@ -97,8 +104,7 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long mask)
 }
 
 // FAST: the physically based estimator (device_math.hpp) on the same rings.  Every light needs its
-// visibility test (SQ is set), a hit goes round once per light with a valid sample as a hit of the
-// reference's estimator does per square light, every segment writes a record (light-sampling
+// visibility test (SQ is set), sent out and joined as described above, every segment writes a record (light-sampling
 // term, what else the segment collected), both already multiplied by the throughput, and the
 // resolve pass is a plain sum; a path that loses the roulette simply sends no ray out.
 template <class R, bool TAB, bool SQ, bool FAST = false>
@@ -108,6 +114,9 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     __shared__ R lds_lights[TAB ? LDS_LIGHTS * LIGHT_STRIDE : 1];
     __shared__ DoneQueue done_queues[BLOCK / 64];
     __shared__ uint16_t free_slots[BLOCK / 64][RING_SLOTS]; // per wave: the record slots no path holds (a stack)
+    // per wave and slot: the visibility tests of the path's current hit that are done (count << 16)
+    // and which of them found a blocker (bit k: test k)
+    __shared__ uint32_t join_words[SQ ? BLOCK / 64 : 1][SQ ? RING_SLOTS : 1];
     for (int k = threadIdx.x; k < (BLOCK / 64) * RING_SLOTS; k += BLOCK)
         free_slots[k / RING_SLOTS][k % RING_SLOTS] = uint16_t(k % RING_SLOTS);
     if (TAB)
@@ -122,7 +131,8 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     const int g = global_wave(), lane = lane_id();
     if (g >= st.n_waves)
         return;
-    const Rings<R> Q(st.rings + size_t(g) * ring_bytes<R>(FAST));
+    constexpr int RQ = SQ ? RING_CAP_TESTS : RING_CAP; // entries of the ray ring
+    const Rings<R, RQ> Q(st.rings + size_t(g) * ring_bytes<R>(FAST, SQ));
     const uint32_t n_paths = uint32_t(B.n_paths);
     uint32_t next = 0, end = 0; // the wave's current range of path ids
     bool drained = false;       // the pool has no ids left (wave-uniform)
@@ -136,6 +146,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     // record slots: a path takes one when its camera ray is admitted and returns it in its resolve
     // pass; at most 192 paths are in flight and at most 127 wait in dq, so the stack never runs dry
     uint16_t *free_slot = free_slots[threadIdx.x >> 6];
+    uint32_t *join = join_words[SQ ? threadIdx.x >> 6 : 0];
     uint32_t free_count = RING_SLOTS; // wave-uniform
     uint32_t slot = 0;                // of the path whose ray this lane traverses
 
@@ -148,6 +159,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     // a visibility test in flight: the hit it belongs to (handed back when the test is done)
     V3<R> vp = {R(0), R(0), R(0)}, vd = {R(0), R(0), R(0)};
     int vtri = -1;
+    uint32_t vcode = 0; // which test of that hit: k << 16 | the hit's number of tests << 20
     uint32_t n_seg = 0, n_iter = 0, n_rec = 0, n_tests = 0;
     uint32_t n_visit[2] = {0, 0};
 #ifdef PTX_PHASE_TIMING
@@ -244,7 +256,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
         const uint32_t e = (hq_head + uint32_t(lane)) % RING_CAP;
         const bool mine = uint32_t(lane) < n;
         bool finished = false, cont = false, defer = false;
-        int defer_light = -1;
+        uint32_t defer_mask = 0; // lights whose segment to this hit needs a visibility test (first visit)
         uint32_t defer_state = 0;
         uint32_t fin_state = 0;
         V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)}, keep_d = {R(0), R(0), R(0)};
@@ -368,10 +380,10 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                             const R cn = dot(nrm, wl);
                             if (!(cn > R(0)))
                                 continue;
-                            if (k_test == tested)
+                            if (tested == 0)
                             {
-                                defer = true, defer_light = l, defer_state = state; // the next test this bounce needs
-                                break;
+                                defer_mask |= 1u << l; // first visit: only find out which tests this hit needs
+                                continue;
                             }
                             const bool blocked = ((state >> (RING_RESULT_SHIFT + k_test)) & 1u) != 0u;
                             k_test++;
@@ -380,6 +392,8 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                             const R w = (go_on && bnc + 1 < depth) ? cn / (pl + pb) : cn / pl;
                             direct = direct + V3<R>{thr.x * L[1] * f.x * w, thr.y * L[2] * f.y * w, thr.z * L[3] * f.z * w};
                         }
+                        if (defer_mask != 0u)
+                            defer = true, defer_state = state; // out they go, all at once
                         if (!defer && go_on)
                         {
                             const R x0 = rng_draw<R>(key, sample, bnc, D0), x1 = rng_draw<R>(key, sample, bnc, D0 + 1);
@@ -422,7 +436,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                             finished = true, fin_state = uint32_t(bnc + 1) << 16;
                     }
                     else
-                        n_tests++;
+                        n_tests += uint32_t(__popc(defer_mask));
                 }
             }
             else if (mat_id < 0)
@@ -476,11 +490,10 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                         continue;
                     if (square)
                     {
-                        if (k_test == tested)
+                        if (tested == 0)
                         {
-                            // the next test this bounce needs: out it goes
-                            defer = true, defer_light = l, defer_state = state;
-                            break;
+                            defer_mask |= 1u << l; // first visit: only find out which tests this hit needs
+                            continue;
                         }
                         const bool blocked = ((state >> (RING_RESULT_SHIFT + k_test)) & 1u) != 0u;
                         k_test++;
@@ -491,6 +504,8 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                     const R w = cn / pdf;
                     direct = direct + V3<R>{(L[1] * w) * f.x, (L[2] * w) * f.y, (L[3] * w) * f.z};
                 }
+                if (defer_mask != 0u)
+                    defer = true, defer_state = state; // out they go, all at once
                 if (!defer)
                 {
                     // ---- next direction and indirect coefficient -----------------------------------------
@@ -509,26 +524,52 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                         finished = true, fin_state = uint32_t(bnc + 1) << 16;
                 }
                 else
-                    n_tests++;
+                    n_tests += uint32_t(__popc(defer_mask));
             }
         }
         hq_head = (hq_head + n) % RING_CAP;
         hq_count -= n;
         // continuation rays -> ray ring
         {
-            // (a lane has a continuation ray, or a visibility test, or neither)
-            const unsigned long long cm = __ballot(cont || defer);
-            if (cont || defer)
+            const unsigned long long cm = __ballot(cont);
+            if (cont)
             {
-                const uint32_t r = (rq_head + rq_count + rank_in(cm)) % RING_CAP;
-                const V3<R> od = defer ? keep_d : wi;
-                Q.ro[r] = p.x, Q.ro[RING_CAP + r] = p.y, Q.ro[2 * RING_CAP + r] = p.z;
-                Q.rd[r] = od.x, Q.rd[RING_CAP + r] = od.y, Q.rd[2 * RING_CAP + r] = od.z;
-                Q.r_slot[r] = s_slot, Q.r_bounce[r] = defer ? defer_state : s_bounce + 1u;
+                const uint32_t r = (rq_head + rq_count + rank_in(cm)) % RQ;
+                Q.ro[r] = p.x, Q.ro[RQ + r] = p.y, Q.ro[2 * RQ + r] = p.z;
+                Q.rd[r] = wi.x, Q.rd[RQ + r] = wi.y, Q.rd[2 * RQ + r] = wi.z;
+                Q.r_slot[r] = s_slot, Q.r_bounce[r] = s_bounce + 1u;
                 if (SQ)
-                    Q.r_tri[r] = keep_tri, Q.r_light[r] = defer ? defer_light : -1;
+                    Q.r_tri[r] = keep_tri, Q.r_light[r] = -1;
             }
             rq_count += uint32_t(__popcll(cm));
+        }
+        // visibility tests -> ray ring, one entry per test (the hit: point, incoming direction,
+        // triangle; which light, which of the hit's tests, how many it has), so that the tests of a
+        // hit run on as many lanes at once; round j writes the j-th test of every lane that has one
+        if constexpr (SQ)
+        {
+            uint32_t rest = defer ? defer_mask : 0u;
+            const uint32_t n_mine = uint32_t(__popc(rest));
+            if (defer)
+                join[s_slot] = 0u;
+            for (uint32_t j = 0;; j++)
+            {
+                const bool has = rest != 0u;
+                const unsigned long long hm = __ballot(has);
+                if (hm == 0ull)
+                    break;
+                if (has)
+                {
+                    const int l = __builtin_ctz(rest);
+                    rest &= rest - 1u;
+                    const uint32_t r = (rq_head + rq_count + rank_in(hm)) % RQ;
+                    Q.ro[r] = p.x, Q.ro[RQ + r] = p.y, Q.ro[2 * RQ + r] = p.z;
+                    Q.rd[r] = keep_d.x, Q.rd[RQ + r] = keep_d.y, Q.rd[2 * RQ + r] = keep_d.z;
+                    Q.r_slot[r] = s_slot, Q.r_bounce[r] = defer_state;
+                    Q.r_tri[r] = keep_tri, Q.r_light[r] = int(uint32_t(l) | (j << 16) | (n_mine << 20));
+                }
+                rq_count += uint32_t(__popcll(hm));
+            }
         }
         // finished paths -> resolve
         {
@@ -580,27 +621,44 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
         {
             const bool give = busy && done;
             const unsigned long long gm = __ballot(give);
-            if (give)
+            // a finished visibility test adds its result to its hit's word; the last of a hit's tests
+            // hands the hit back, all results in its state word
+            bool hand = give;
+            uint32_t word = bounce;
+            if constexpr (SQ)
             {
-                const uint32_t r = (hq_head + hq_count + rank_in(gm)) % RING_CAP;
-                const bool test = SQ && T.any != 0; // a finished visibility test hands its hit back, marked
+                if (give && T.any != 0)
+                {
+                    const uint32_t k = (vcode >> 16) & 15u, of = (vcode >> 20) & 15u;
+                    const uint32_t add = (1u << 16) | (T.target == 1 ? 1u << k : 0u);
+                    const uint32_t old = atomicAdd(&join[slot], add);
+                    hand = (old >> 16) + 1u == of;
+                    word = (bounce & RING_BOUNCE) | (of << RING_TESTS_SHIFT) | (((old + add) & 0xFFFu) << RING_RESULT_SHIFT);
+                }
+            }
+            const unsigned long long pm = __ballot(hand);
+            if (hand)
+            {
+                const uint32_t r = (hq_head + hq_count + rank_in(pm)) % RING_CAP;
+                const bool test = SQ && T.any != 0;
                 const V3<R> p = test ? vp : o + T.best_t * d;
                 const V3<R> hd = test ? vd : d;
                 Q.hp[r] = p.x, Q.hp[RING_CAP + r] = p.y, Q.hp[2 * RING_CAP + r] = p.z;
                 Q.hd[r] = hd.x, Q.hd[RING_CAP + r] = hd.y, Q.hd[2 * RING_CAP + r] = hd.z;
                 Q.h_tri[r] = test ? vtri : T.target;
                 Q.h_slot[r] = slot;
-                // a test adds its result bit and counts itself
-                const uint32_t k = (bounce >> RING_TESTS_SHIFT) & 15u;
-                Q.h_bounce[r] = test ? ((bounce | (T.target == 1 ? 1u << (RING_RESULT_SHIFT + k) : 0u)) + (1u << RING_TESTS_SHIFT)) : bounce;
-                busy = false, done = false;
+                Q.h_bounce[r] = word;
             }
-            hq_count += uint32_t(__popcll(gm));
+            if (give)
+                busy = false, done = false;
+            hq_count += uint32_t(__popcll(pm));
             n_busy -= __popcll(gm);
         }
         PTX_PHASE_END(2);
         // ---- 64 hits wait: shade them (fewer only when nothing else is left to do) -----------------
-        if (hq_count >= 64u)
+        // (with visibility tests a pass may add an entry per tested light and hit to the ray ring: it
+        // waits for that much room, while the lanes go on taking rays)
+        if (hq_count >= 64u && (!SQ || rq_count + 64u * uint32_t(FAST ? S.n_lights : S.n_square) <= uint32_t(RQ)))
             shade(64u);
         else if (hq_count > 0u && n_busy == 0 && rq_count == 0u && drained)
             shade(hq_count);
@@ -628,9 +686,9 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 V3<R> co, cd;
                 primary_ray<R>(cam, col, row, co, cd);
                 const uint64_t key = rng_pixel_key(B.seed, uint32_t(row) * uint32_t(B.image_width) + uint32_t(col));
-                const uint32_t r = (rq_head + rq_count + uint32_t(lane)) % RING_CAP;
-                Q.ro[r] = cam_pos.x, Q.ro[RING_CAP + r] = cam_pos.y, Q.ro[2 * RING_CAP + r] = cam_pos.z;
-                Q.rd[r] = cd.x, Q.rd[RING_CAP + r] = cd.y, Q.rd[2 * RING_CAP + r] = cd.z;
+                const uint32_t r = (rq_head + rq_count + uint32_t(lane)) % RQ;
+                Q.ro[r] = cam_pos.x, Q.ro[RQ + r] = cam_pos.y, Q.ro[2 * RQ + r] = cam_pos.z;
+                Q.rd[r] = cd.x, Q.rd[RQ + r] = cd.y, Q.rd[2 * RQ + r] = cd.z;
                 const uint32_t sl = free_slot[free_count - 1u - uint32_t(lane)];
                 Q.r_slot[r] = sl, Q.r_bounce[r] = 0u;
                 Q.s_pid[sl] = id, Q.s_klo[sl] = uint32_t(key), Q.s_khi[sl] = uint32_t(key >> 32);
@@ -650,13 +708,15 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             const uint32_t rk = rank_in(fm);
             if (!busy && rk < rq_count)
             {
-                const uint32_t r = (rq_head + rk) % RING_CAP;
-                o = {Q.ro[r], Q.ro[RING_CAP + r], Q.ro[2 * RING_CAP + r]};
-                d = {Q.rd[r], Q.rd[RING_CAP + r], Q.rd[2 * RING_CAP + r]};
+                const uint32_t r = (rq_head + rk) % RQ;
+                o = {Q.ro[r], Q.ro[RQ + r], Q.ro[2 * RQ + r]};
+                d = {Q.rd[r], Q.rd[RQ + r], Q.rd[2 * RQ + r]};
                 bounce = Q.r_bounce[r], slot = Q.r_slot[r];
-                const int test_light = SQ ? Q.r_light[r] : -1;
-                if (SQ && test_light >= 0)
+                const int test_code = SQ ? Q.r_light[r] : -1;
+                const int test_light = test_code & 0xFFFF;
+                if (SQ && test_code >= 0)
                 {
+                    vcode = uint32_t(test_code);
                     // a visibility test: the entry is the hit (point, incoming direction, triangle); the
                     // segment runs from the light sample point, a function of the path's random numbers,
                     // to the shaded point, as in visible()
@@ -688,8 +748,10 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                 busy = true, done = false;
             }
             const uint32_t taken = min(uint32_t(__popcll(fm)), rq_count);
-            rq_head = (rq_head + taken) % RING_CAP;
+            rq_head = (rq_head + taken) % RQ;
             rq_count -= taken;
+            if (rq_count == 0u)
+                rq_head = 0u; // an empty ring starts over: the entries in use stay in a few cache lines
             n_busy += int(taken);
         }
         PTX_PHASE_END(6);

@@ -654,6 +654,7 @@ template <class R> struct TracePlan
     size_t dyn_lds = 0; // bytes of traversal stacks per workgroup (BVH kernels)
     int stack_levels = 0; // levels of them
     bool rings = false;   // the ring tracer (needs DState::rings)
+    bool ring_tests = false; // ... compiled with visibility tests (a longer ray ring)
 };
 
 template <class R, bool BRUTE>
@@ -714,7 +715,7 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
     }
     if (!BRUTE && fast && rings)
     {
-        p.rings = true;
+        p.rings = true, p.ring_tests = true;
         if constexpr (sizeof(R) == 8)
             p.kernel = tab ? k_trace_rings_fast_f64<true> : k_trace_rings_fast_f64<false>;
         else
@@ -723,12 +724,13 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
         std::snprintf(nm, sizeof(nm), "k_trace_rings_fast_%s<%s>", sizeof(R) == 8 ? "f64" : "f32", tab ? "true" : "false");
         p.name = nm;
     }
-    else if (!BRUTE && S.n_square <= 12 && rings)
+    else if (!BRUTE && S.n_square <= RING_MAX_TESTS && (S.n_square == 0 || S.n_lights <= 32) && rings)
     {
         // the tracer that keeps more paths in flight than lanes (its state word counts up to 12
-        // visibility tests per bounce)
+        // visibility tests per bounce, and a shading pass names the lights to test in a 32-bit set)
         p.rings = true;
         const bool sq = S.n_square >= 1;
+        p.ring_tests = sq;
         if constexpr (sizeof(R) == 8)
             p.kernel = tab ? (sq ? k_trace_rings_f64<true, true> : k_trace_rings_f64<true, false>)
                            : (sq ? k_trace_rings_f64<false, true> : k_trace_rings_f64<false, false>);
@@ -935,7 +937,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
         need.paths = cap, need.depth = depth;
         need.waves = grid_blocks * (BLOCK / 64);
         need.slots = plan.rings ? RING_SLOTS : LANE_SLOTS;
-        need.ring_bytes = plan.rings ? ring_bytes<R>(fast) : 0;
+        need.ring_bytes = plan.rings ? ring_bytes<R>(fast, plan.ring_tests) : 0;
         need.spill_levels = brute_ ? 0 : std::max(geo_->stack_need - plan.stack_levels, 0);
         need.ring_batch = ring_batch;
         if (im.layout_state(nullptr, need, &spill) <= budget)
