@@ -58,6 +58,27 @@ def test_static_state_render_equals_allocating_render(root):
     assert np.array_equal(out.cpu().numpy(), full)
 
 
+def test_static_state_render_with_visibility_tests_in_the_rings(root):
+    """The physically based estimator on a BVH scene (every light tested: the longer ray ring) and a
+    BVH scene with square lights under the reference's estimator: the static region holds a smaller
+    grid of them, with the same results as the allocating entry point."""
+    s, _ = load(root, "config/mis.conf", width=96, height=64, spp=3)
+    c = make_ctx(s)
+    for mode in ("f64", "f32"):
+        a, b, sa, sb = both(c, (64, 96, 3), mode=mode, estimator="fast")
+        assert c.last_kernel().startswith("k_trace_rings_fast")
+        assert sa["state_bytes"] <= 256 << 20
+        if mode == "f64":
+            assert np.abs(a - b).max() <= 1e-9 * max(1.0, float(b.max())) and a.max() > 0
+        assert all(sa[k] == sb[k] for k in ("paths", "segments", "shadow_rays", "records"))
+    s2, _ = load(root, "config/cbox.conf", width=64, height=48, spp=4)
+    c2 = pt.Context(0, brute_force_limit=0)                                    # the Cornell box on the BVH: its square light is tested through the rings
+    c2.build_accel(s2)
+    a, b, sa, sb = both(c2, (48, 64, 3), mode="f64")
+    assert c2.last_kernel() == "k_trace_rings_f64<true, true>"
+    assert np.array_equal(a, b) and sa["shadow_rays"] == sb["shadow_rays"] > 0
+
+
 def test_static_state_render_rejects_what_does_not_fit(root):
     s, _ = load(root, "config/cbox.conf", width=1024, height=64, spp=1)
     c = make_ctx(s)
