@@ -154,14 +154,16 @@ int ptx_context_set_stream(ptx_context *, void *hip_stream);
 void ptx_context_destroy(ptx_context *);
 /* Tunables: "brute_force_limit" (scenes with at most this many triangles use the all-triangles
  * intersector instead of the BVH; default and maximum 64), "default_batch_paths" (paths per
- * tracer launch; default 2^26), "chunk_paths" (path ids a wave of the tracer takes from the pool at
+ * tracer launch; default 2^25, less when the device's free memory asks for it), "chunk_paths" (path ids a wave of the tracer takes from the pool at
  * a time, 64..65536), "trace_blocks_per_cu" (workgroups of the tracer per compute unit; 0 = what
  * the occupancy calculator reports), "shadow_queue" (1/0: park the visibility tests of
  * one-square-light scenes in the per-wave LDS queue, or run them in place), "lds_stack_levels"
  * (BVH scenes: at most this many traversal stack levels per lane in LDS, deeper ones in a global
- * array; 0 = as many as fit at full occupancy), "bvh_rings" (1/0: BVH scenes with at most one square light are
- * traced with per-wave hit and ray rings -- more paths in flight than lanes, shading on full waves
- * -- or with one path per lane).  Results do not depend on any of them.  Set before
+ * array; 0 = as many as fit at full occupancy), "bvh_rings" (1/0: BVH scenes with at most 12 lights that need
+ * visibility tests are traced with per-wave hit and ray rings -- more paths in flight than lanes,
+ * shading on full waves -- or with one path per lane), "ring_batch" (1..64: lanes of a wave of that
+ * tracer that hand over hits / take rays together; default 40).  Results do not depend on any of
+ * them.  Set before
  * ptx_build_accel. */
 int ptx_context_set_option(ptx_context *, const char *name, int64_t value);
 int ptx_build_accel(ptx_context *, const ptx_scene *);
