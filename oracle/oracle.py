@@ -301,8 +301,12 @@ class RefAccel:
     RefAccel(verts, "AABB", subdivide) is cAABB, RefAccel(verts, "OCTREE", capacity) is cOctree
     (src/geometry/cAccelStruct.cpp:89-263, 266-482, 614-730 of the reference)."""
 
-    def __init__(self, verts, kind, param):
+    def __init__(self, verts, kind, param, octree_file=None):
         L = lib()
+        L.orc_octree_write.restype = C.c_int
+        L.orc_octree_write.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_octree_read.restype = C.c_void_p
+        L.orc_octree_read.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_void_p]
         L.orc_accel_build.restype = C.c_void_p
         L.orc_accel_build.argtypes = [C.c_void_p, C.c_int32, C.c_int, C.c_int]
         L.orc_accel_free.argtypes = [C.c_void_p]
@@ -311,9 +315,27 @@ class RefAccel:
         L.orc_accel_vistest_many.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         self.verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 9)
         self.kind = kind
+        if octree_file is not None:
+            # cOctree::ReadOctree (src/geometry/cAccelStruct.cpp:524-611): the structure as its cache holds it
+            st = C.c_int(0)
+            self._h = L.orc_octree_read(_p(self.verts), self.verts.shape[0], os.fsencode(octree_file), C.byref(st))
+            if not self._h:
+                raise RuntimeError({1: "cannot open %s" % octree_file, 2: "node id beyond the reader's buffer (the reference exits here)",
+                                    3: "malformed .octree file"}.get(st.value, "octree read failed"))
+            return
         self._h = L.orc_accel_build(_p(self.verts), self.verts.shape[0], {"AABB": 1, "OCTREE": 2}[kind], int(param))
         if not self._h:
             raise RuntimeError("octree split recursion does not end (the reference overflows its stack here)")
+
+    @classmethod
+    def from_octree_file(cls, verts, path):
+        return cls(verts, "OCTREE", 0, octree_file=path)
+
+    def write_octree(self, path):
+        """cOctree::WriteOctree (src/geometry/cAccelStruct.cpp:485-520): the text cache the reference
+        keeps beside the mesh."""
+        if lib().orc_octree_write(self._h, os.fsencode(path)) != 0:
+            raise RuntimeError("cannot write %s (not an octree, or the file cannot be opened)" % path)
 
     def __del__(self):
         if getattr(self, "_h", None):

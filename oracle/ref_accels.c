@@ -21,13 +21,19 @@
  *   - a split never ends when `capacity` faces all meet one ever smaller box (that many faces
  *     round one vertex): the reference overflows its stack, here the build gives up at depth 48;
  *   - both structures visit boxes in storage order and keep the FIRST of equally distant hits,
- *     the plain loop keeps the lowest face id.
+ *     the plain loop keeps the lowest face id;
+ *   - the octree is cached beside the mesh as text (`<mesh path>.octree`, cAccelStruct.cpp:485-611):
+ *     one line per node in breadth-first order with the box bounds printed at the stream's default
+ *     six significant digits, so an octree READ from its cache culls with boxes that differ from
+ *     the ones it was built with (orc_octree_write / orc_octree_read restate both directions; the
+ *     reference ships no .octree file, so the format is pinned by its writer's source alone).
  * PARITY STATUS: unpinned (the reference holds no vectors for these structures and cannot be built
  * here); Eigen's reductions are restated with left-to-right sums.
  */
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -46,6 +52,7 @@ typedef struct node_s
     struct node_s *child[8]; /* Children[x][y][z] at x*4 + y*2 + z */
     box_t box;
     int leaf;
+    int32_t id; /* tOctreeNode::id: nodes are numbered as they are created */
 } node_t;
 
 typedef struct
@@ -230,6 +237,7 @@ static node_t *node_new(accel_t *A, double b[3][2])
     node_t *n = (node_t *)calloc(1, sizeof(node_t));
     memcpy(n->box.b, b, sizeof(n->box.b));
     n->leaf = 1;
+    n->id = A->n_all;
     if (A->n_all == A->cap_all)
     {
         A->cap_all = A->cap_all ? 2 * A->cap_all : 64;
@@ -578,4 +586,180 @@ void orc_accel_vistest_many(const accel_t *A, int64_t n, const double *p1, const
 #pragma omp parallel for schedule(dynamic, 256)
     for (int64_t i = 0; i < n; i++)
         vis[i] = orc_accel_vistest(A, p1 + i * 3, p2 + i * 3);
+}
+
+/* ---- the .octree cache (cOctree::WriteOctree / ReadOctree, cAccelStruct.cpp:485-611) ----------
+ * Line of a node: id, leaf flag, the three (low, high) bound pairs, then the eight child ids in
+ * Children[x][y][z] order (inner node) or the face ids (leaf), every item followed by one space.
+ * A bound pair is printed the way Eigen prints a row vector to a stream of default precision:
+ * six significant digits, the two numbers padded on the left to the width of the longer one. */
+static void print_pair(FILE *f, double lo, double hi)
+{
+    char a[64], b[64];
+    snprintf(a, sizeof(a), "%g", lo);
+    snprintf(b, sizeof(b), "%g", hi);
+    int w = (int)strlen(a) > (int)strlen(b) ? (int)strlen(a) : (int)strlen(b);
+    fprintf(f, "%*s %*s ", w, a, w, b);
+}
+
+/* 0: written; 1: not an octree / cannot open the file */
+int orc_octree_write(const accel_t *A, const char *path)
+{
+    if (!A || A->type != 2 || !A->root)
+        return 1;
+    FILE *f = fopen(path, "w");
+    if (!f)
+        return 1;
+    /* breadth first from the root, as the reference's queue does */
+    const node_t **queue = (const node_t **)malloc(sizeof(node_t *) * (size_t)(A->n_all > 0 ? A->n_all : 1));
+    int32_t head = 0, tail = 0;
+    queue[tail++] = A->root;
+    while (head < tail)
+    {
+        const node_t *n = queue[head++];
+        fprintf(f, "%d %d ", (int)n->id, n->leaf ? 1 : 0);
+        for (int i = 0; i < 3; i++)
+            print_pair(f, n->box.b[i][0], n->box.b[i][1]);
+        if (!n->leaf)
+            for (int c = 0; c < 8; c++)
+                fprintf(f, "%d ", (int)n->child[c]->id), queue[tail++] = n->child[c];
+        else
+            for (int32_t i = 0; i < n->box.n; i++)
+                fprintf(f, "%d ", (int)n->box.faces[i]);
+        fprintf(f, "\n");
+    }
+    free(queue);
+    fclose(f);
+    return 0;
+}
+
+#define OCTREE_READ_IDS 1000000 /* buffer_num of the reference's reader: larger ids end the process there */
+
+/* Reads a cache file into a structure that answers queries like a built octree.  *status: 0 read;
+ * 1 cannot open; 2 an id beyond the reference's buffer (it prints "buffer exceed" and exits);
+ * 3 no node 0 / a face id outside the mesh / a malformed line.  verts must outlive the result. */
+accel_t *orc_octree_read(const double *verts, int32_t n_tris, const char *path, int *status)
+{
+    int st_local = 0;
+    if (!status)
+        status = &st_local;
+    *status = 0;
+    FILE *f = fopen(path, "r");
+    if (!f)
+    {
+        *status = 1;
+        return NULL;
+    }
+    accel_t *A = (accel_t *)calloc(1, sizeof(accel_t));
+    A->type = 2, A->verts = verts, A->n_tris = n_tris;
+    node_t **by_id = (node_t **)calloc((size_t)OCTREE_READ_IDS + 1, sizeof(node_t *));
+    char *line = NULL;
+    size_t cap = 0;
+    while (*status == 0)
+    {
+        /* a line of any length */
+        size_t len = 0;
+        int ch;
+        while ((ch = fgetc(f)) != EOF && ch != '\n')
+        {
+            if (len + 2 > cap)
+                cap = cap ? 2 * cap : 256, line = (char *)realloc(line, cap);
+            line[len++] = (char)ch;
+        }
+        if (len == 0 && ch == EOF)
+            break;
+        if (cap == 0)
+            cap = 256, line = (char *)realloc(line, cap);
+        line[len] = 0;
+        char *p = line, *e;
+        long id = strtol(p, &e, 10);
+        if (e == p)
+            break; /* the reader stops at the first line without a node id */
+        p = e;
+        long leaf = strtol(p, &e, 10);
+        if (e == p)
+        {
+            *status = 3;
+            break;
+        }
+        p = e;
+        if (id < 0 || id > OCTREE_READ_IDS)
+        {
+            *status = 2;
+            break;
+        }
+        double b[3][2];
+        int ok = 1;
+        for (int i = 0; i < 3 && ok; i++)
+            for (int j = 0; j < 2 && ok; j++)
+            {
+                b[i][j] = strtod(p, &e);
+                ok = e != p;
+                p = e;
+            }
+        if (!ok)
+        {
+            *status = 3;
+            break;
+        }
+        node_t *n = by_id[id];
+        if (!n)
+            n = by_id[id] = node_new(A, b);
+        else
+            memcpy(n->box.b, b, sizeof(b)); /* made earlier as somebody's child, with a placeholder box */
+        n->id = (int32_t)id;
+        n->leaf = leaf != 0;
+        if (!n->leaf)
+        {
+            for (int c = 0; c < 8 && *status == 0; c++)
+            {
+                long cid = strtol(p, &e, 10);
+                if (e == p)
+                    *status = 3;
+                else if (cid < 0 || cid > OCTREE_READ_IDS)
+                    *status = 2;
+                else
+                {
+                    if (!by_id[cid])
+                        by_id[cid] = node_new(A, b), by_id[cid]->id = (int32_t)cid;
+                    n->child[c] = by_id[cid];
+                }
+                p = e;
+            }
+        }
+        else
+        {
+            for (;;)
+            {
+                long face = strtol(p, &e, 10);
+                if (e == p)
+                    break;
+                p = e;
+                if (face < 0 || face >= n_tris)
+                {
+                    *status = 3;
+                    break;
+                }
+                box_push(&n->box, (int32_t)face);
+            }
+        }
+    }
+    free(line);
+    fclose(f);
+    A->root = by_id[0];
+    if (*status == 0 && !A->root)
+        *status = 3;
+    /* an inner node whose line never came keeps null children: refuse it rather than crash in a query */
+    for (int32_t i = 0; i < A->n_all && *status == 0; i++)
+        if (!A->all[i]->leaf)
+            for (int c = 0; c < 8; c++)
+                if (!A->all[i]->child[c])
+                    *status = 3;
+    free(by_id);
+    if (*status != 0)
+    {
+        orc_accel_free(A);
+        return NULL;
+    }
+    return A;
 }

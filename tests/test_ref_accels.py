@@ -121,3 +121,65 @@ def test_room_stand_in_loads_into_the_reference_octree(root, room_scene):
     ids, pts = O.first_hit(with_points=True)
     got_ids, got_pts = A.raycast(o, d)
     assert np.array_equal(got_ids, ids) and np.array_equal(got_pts[ids >= 0], pts[ids >= 0])
+
+
+def test_octree_cache_round_trip(cbox_rays, tmp_path):
+    """cOctree::WriteOctree / ReadOctree (src/geometry/cAccelStruct.cpp:485-611): the text cache the
+    reference keeps beside the mesh.  One line per node, breadth first: id, leaf flag, three
+    (low, high) pairs at six significant digits, then eight child ids or the face ids, every item
+    followed by a space.  Read back, the octree has the same nodes and faces and answers this
+    scene's rays like the one that was built (its boxes differ in the seventh digit).  The reference
+    ships no .octree file: the format is pinned by its writer's source alone."""
+    ref, O, (o, d, ids, pts), (o2, d2, ids2, pts2) = cbox_rays
+    A = oracle.RefAccel(ref.verts, "OCTREE", 8)
+    path = tmp_path / "cbox.obj.octree"
+    A.write_octree(str(path))
+    lines = path.read_text().split("\n")
+    assert lines[-1] == "" and len(lines) - 1 == A.info()["boxes"] == 49
+    first = lines[0].split()
+    assert first[:2] == ["0", "0"] and [float(x) for x in first[2:8]] == [-1e-05, 5.56001, -1e-05, 5.48801, -1e-05, 5.59201]
+    assert first[8:] == [str(k) for k in range(1, 9)]                   # the root's children are the next eight nodes made
+    assert all(ln.endswith(" ") for ln in lines[:-1])
+    seen, faces = set(), 0
+    for ln in lines[:-1]:
+        f = ln.split()
+        assert int(f[0]) not in seen
+        seen.add(int(f[0]))
+        assert all(float("%g" % float(x)) == float(x) for x in f[2:8])  # six significant digits
+        if f[1] == "0":
+            assert len(f) == 16
+        else:
+            faces += len(f) - 8
+            assert all(0 <= int(x) < 26 for x in f[8:])
+    assert faces == A.info()["face_refs"] == 157
+    B = oracle.RefAccel.from_octree_file(ref.verts, str(path))
+    assert B.info() == A.info()
+    for ro, rd in ((o, d), (o2, d2)):
+        a_ids, a_pts = A.raycast(ro, rd)
+        b_ids, b_pts = B.raycast(ro, rd)
+        assert np.array_equal(a_ids, b_ids) and np.array_equal(a_pts, b_pts, equal_nan=True)
+    # written again from what was read, the file only differs where a bound had more digits to lose
+    path2 = tmp_path / "again.octree"
+    B.write_octree(str(path2))
+    assert path2.read_text() == path.read_text()
+
+
+def test_octree_cache_reader_errors(cbox_rays, tmp_path):
+    ref = cbox_rays[0]
+    with pytest.raises(RuntimeError, match="cannot open"):
+        oracle.RefAccel.from_octree_file(ref.verts, str(tmp_path / "missing.octree"))
+    p = tmp_path / "big.octree"
+    p.write_text("0 0 0 1 0 1 0 1 1 2 3 4 5 6 7 1000001 \n")             # the reference prints "buffer exceed" and exits
+    with pytest.raises(RuntimeError, match="buffer"):
+        oracle.RefAccel.from_octree_file(ref.verts, str(p))
+    p.write_text("0 1 0 1 0 1 0 1 3 99 \n")                               # a face the mesh does not have
+    with pytest.raises(RuntimeError, match="malformed"):
+        oracle.RefAccel.from_octree_file(ref.verts, str(p))
+    p.write_text("1 1 0 1 0 1 0 1 3 \n")                                  # no node 0: nothing to start a query at
+    with pytest.raises(RuntimeError, match="malformed"):
+        oracle.RefAccel.from_octree_file(ref.verts, str(p))
+    p.write_text("0 1  -1 6 -1 6 -1 6 " + " ".join(str(k) for k in range(26)) + " \n\n")
+    one = oracle.RefAccel.from_octree_file(ref.verts, str(p))            # a single leaf with every face: the plain loop
+    assert one.info()["boxes"] == 1 and one.info()["face_refs"] == 26
+    with pytest.raises(RuntimeError):
+        oracle.RefAccel(ref.verts, "AABB", 2).write_octree(str(tmp_path / "grid.octree"))

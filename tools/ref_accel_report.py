@@ -8,6 +8,7 @@ cast through the plain loop (oracle/pt_oracle.c) and through the restated struct
 import json
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -65,6 +66,25 @@ def report(conf, width=128, n_bounce=20000, structures=None):
         out["structures"]["%s %d" % (kind, param)] = dict(
             A.info(), build_and_query_s=round(time.perf_counter() - t0, 2),
             camera=compare(ids, pts, a_ids, a_pts, o), secondary=compare(ids2, pts2, b_ids, b_pts, o2))
+        if kind == "OCTREE":
+            # the same octree as the reference finds it on its next start: written to its text cache
+            # (bounds at six significant digits) and read back
+            with tempfile.TemporaryDirectory() as tmp:
+                path = os.path.join(tmp, "mesh.obj.octree")
+                A.write_octree(path)
+                size = os.path.getsize(path)
+                try:
+                    B = oracle.RefAccel.from_octree_file(ref.verts, path)
+                except RuntimeError as e:
+                    out["structures"]["%s %d, read back from its cache" % (kind, param)] = {"error": str(e), "cache_bytes": size}
+                    continue
+            c_ids, c_pts = B.raycast(o, d)
+            d_ids, d_pts = B.raycast(o2, d2)
+            out["structures"]["%s %d, read back from its cache" % (kind, param)] = dict(
+                B.info(), cache_bytes=size,
+                camera=compare(ids, pts, c_ids, c_pts, o), secondary=compare(ids2, pts2, d_ids, d_pts, o2),
+                camera_rays_answered_unlike_the_built_octree=int(((c_ids != a_ids) | ((c_pts != a_pts).any(1) & (c_ids >= 0))).sum()),
+                secondary_rays_answered_unlike_the_built_octree=int(((d_ids != b_ids) | ((d_pts != b_pts).any(1) & (d_ids >= 0))).sum()))
     return out
 
 
