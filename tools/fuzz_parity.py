@@ -12,7 +12,7 @@ noise that can land inside the acceptance window at a point well away from the t
 all-triangles intersector runs the same arithmetic on every face and reproduces that; the BVH only
 visits triangles whose box the ray meets.
 
-    python tools/fuzz_parity.py [--seeds 40] [--first 0] [--rays 6000]
+    python tools/fuzz_parity.py [--seeds 40] [--first 0] [--rays 6000] [--max-faces 3000]
 """
 import argparse
 import copy
@@ -102,9 +102,9 @@ def rays(rng, verts, n):
     return o, d / nrm, on
 
 
-def one(seed, n_rays, template):
+def one(seed, n_rays, template, max_faces=3000):
     rng = np.random.default_rng(seed)
-    n = int(rng.choice([rng.integers(1, 65), rng.integers(65, 400), rng.integers(400, 3000)]))
+    n = int(rng.choice([rng.integers(1, 65), rng.integers(65, 400), rng.integers(400, max(max_faces, 401))]))
     ref = copy.deepcopy(template)
     ref.verts = soup(rng, n).reshape(-1, 3, 3)
     ref.normals = np.full_like(ref.verts, np.nan)
@@ -151,11 +151,12 @@ def main():
     ap.add_argument("--seeds", type=int, default=40)
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--rays", type=int, default=6000)
+    ap.add_argument("--max-faces", type=int, default=3000)
     a = ap.parse_args()
     template = scene_io.load_conf(os.path.join(ROOT, "config/cbox.conf"), root_dir=ROOT, width=8, height=8, spp=1)
     total = sing = 0
     for seed in range(a.first, a.first + a.seeds):
-        n, bad, hit, vis, s1 = one(seed, a.rays, template)
+        n, bad, hit, vis, s1 = one(seed, a.rays, template, a.max_faces)
         total += bad
         sing += s1
         print("seed %d: %d faces, %.0f%% of the rays hit, %.0f%% of the segments clear, %d differences%s" % (
