@@ -1,0 +1,100 @@
+"""The headline configuration at its full size against the CPU oracle: config/cbox.conf at
+1024 x 1024 with 256 samples per pixel (2.7e8 paths) rendered in f64 on the GPU and by the oracle
+(all host threads), compared pixel by pixel.  Pixels beyond 1e-9 are counted, and a sample of them is
+put through the proof the parity tests use: every sample of the pixel is rendered alone on the GPU
+and re-traced by the oracle, and where the two differ the oracle's path must contain a closest-hit
+search whose two best candidates are within 1e-10 of each other (a tie).  Prints one JSON line.
+
+    python tools/full_config_cbox.py [--spp 256] [--size 1024] [--prove 40]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch  # before the library: both bring a HIP runtime, and torch wants its own loaded first
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pathtracer_amd as pt  # noqa: E402
+from oracle import oracle, scene_io  # noqa: E402
+
+TOL, TIE_GAP = 1e-9, 1e-10
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--prove", type=int, default=40)
+    a = ap.parse_args()
+    kw = dict(width=a.size, height=a.size, spp=a.spp)
+    s = pt.Scene.load_conf(os.path.join(ROOT, "config/cbox.conf"), root_dir=ROOT, **kw)
+    ref = scene_io.load_conf(os.path.join(ROOT, "config/cbox.conf"), root_dir=ROOT, **kw)
+    c = pt.Context(0)
+    c.build_accel(s)
+    t0 = time.time()
+    img, st = c.render(mode="f64", seed=13)
+    t_gpu = time.time() - t0
+    print("GPU frame done in %.1f s" % t_gpu, file=sys.stderr, flush=True)
+    O = oracle.Oracle(ref, seed=13)
+    t0 = time.time()
+    oimg = np.zeros_like(img)
+    ost = {"paths": 0, "segments": 0}
+    rows = 64
+    for r0 in range(0, a.size, rows):                      # in row bands, to show progress
+        ref.region = (r0, 0, min(r0 + rows, a.size) - 1, a.size - 1)
+        Ob = oracle.Oracle(ref, seed=13)
+        part, pst = Ob.render(stats=True)
+        oimg[r0:r0 + rows] = part[r0:r0 + rows]
+        for k in ost:
+            ost[k] += int(pst[k])
+        print("oracle rows %d.. done (%.0f s)" % (r0, time.time() - t0), file=sys.stderr, flush=True)
+    t_cpu = time.time() - t0
+    diff = np.abs(img - oimg).max(axis=-1)
+    bad = np.argwhere(diff > TOL)
+    rec = {"config": "config/cbox.conf at %d x %d, %d spp, depth %d, f64" % (a.size, a.size, a.spp, ref.depth),
+           "paths": int(st["paths"]), "gpu_seconds": round(t_gpu, 2), "oracle_seconds": round(t_cpu, 1),
+           "oracle_threads": int(os.environ.get("OMP_NUM_THREADS", "0")) or os.cpu_count(),
+           "segments_gpu": int(st["segments"]), "segments_oracle": ost["segments"],
+           "pixels": int(diff.size), "pixels_beyond_1e-9": int(len(bad)), "largest_difference": float(diff.max()),
+           "rmse_rel": float(oracle.rmse_rel(img, oimg))}
+    ref.region = (0, 0, a.size - 1, a.size - 1)
+    proven = unexplained = 0
+    pick = bad[np.random.default_rng(13).permutation(len(bad))[: a.prove]] if len(bad) else np.zeros((0, 2), dtype=np.int64)
+    if len(pick):
+        dev = torch.zeros((a.size, a.size, 3), dtype=torch.float64, device="cuda")
+        by_row = {}
+        for y, x in pick:
+            by_row.setdefault(int(y), []).append(int(x))
+        done = 0
+        for y, xs in sorted(by_row.items()):
+            differs = {x: False for x in xs}
+            ok = {x: True for x in xs}
+            for smp in range(a.spp):
+                # the row's pixels, this sample alone (one launch, one row copied back)
+                c.render_device(dev.data_ptr(), mode="f64", spp=1, sample_offset=smp, spp_total=1, rows=(y, y + 1), seed=13)
+                row = dev[y].cpu().numpy()
+                for x in xs:
+                    rgb, faces, margins = O.trace_sample(x, y, smp)
+                    if np.abs(row[x] - rgb).max() > TOL:
+                        differs[x] = True
+                        ok[x] = ok[x] and bool(margins.size and margins.min() <= TIE_GAP)
+            for x in xs:
+                if differs[x] and ok[x]:
+                    proven += 1
+                else:
+                    unexplained += 1
+                    print("pixel (%d, %d): NOT EXPLAINED" % (y, x), file=sys.stderr, flush=True)
+            done += len(xs)
+            if done % 50 < len(xs):
+                print("%d of %d pixels put to the proof" % (done, len(pick)), file=sys.stderr, flush=True)
+    rec.update(pixels_put_to_the_proof=int(len(pick)), proven_ties=proven, not_explained=unexplained)
+    print(json.dumps(rec), flush=True)
+    return 0 if unexplained == 0 else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
