@@ -5,7 +5,7 @@ put through the proof the parity tests use: every sample of the pixel is rendere
 and re-traced by the oracle, and where the two differ the oracle's path must contain a closest-hit
 search whose two best candidates are within 1e-10 of each other (a tie).  Prints one JSON line.
 
-    python tools/full_config_cbox.py [--spp 256] [--size 1024] [--prove 40]
+    python tools/full_config_cbox.py [--spp 256] [--size 1024] [--prove 40] [--conf config/mis.conf --width 768 --height 512]
 """
 import argparse
 import json
@@ -28,11 +28,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--conf", default="config/cbox.conf", help="another scene file: the same check on it")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--prove", type=int, default=40)
     a = ap.parse_args()
-    kw = dict(width=a.size, height=a.size, spp=a.spp)
-    s = pt.Scene.load_conf(os.path.join(ROOT, "config/cbox.conf"), root_dir=ROOT, **kw)
-    ref = scene_io.load_conf(os.path.join(ROOT, "config/cbox.conf"), root_dir=ROOT, **kw)
+    W, H = a.width or a.size, a.height or a.size
+    kw = dict(width=W, height=H, spp=a.spp)
+    s = pt.Scene.load_conf(os.path.join(ROOT, a.conf), root_dir=ROOT, **kw)
+    ref = scene_io.load_conf(os.path.join(ROOT, a.conf), root_dir=ROOT, **kw)
+    if ref.verts.shape[0] > 256:
+        ref.use_bvh = True                                 # the oracle's own culling tree; same hits as its plain loop
     c = pt.Context(0)
     c.build_accel(s)
     t0 = time.time()
@@ -44,8 +50,8 @@ def main():
     oimg = np.zeros_like(img)
     ost = {"paths": 0, "segments": 0}
     rows = 64
-    for r0 in range(0, a.size, rows):                      # in row bands, to show progress
-        ref.region = (r0, 0, min(r0 + rows, a.size) - 1, a.size - 1)
+    for r0 in range(0, H, rows):                           # in row bands, to show progress
+        ref.region = (r0, 0, min(r0 + rows, H) - 1, W - 1)
         Ob = oracle.Oracle(ref, seed=13)
         part, pst = Ob.render(stats=True)
         oimg[r0:r0 + rows] = part[r0:r0 + rows]
@@ -55,17 +61,18 @@ def main():
     t_cpu = time.time() - t0
     diff = np.abs(img - oimg).max(axis=-1)
     bad = np.argwhere(diff > TOL)
-    rec = {"config": "config/cbox.conf at %d x %d, %d spp, depth %d, f64" % (a.size, a.size, a.spp, ref.depth),
+    rec = {"config": "%s at %d x %d, %d spp, depth %d, f64" % (a.conf, W, H, a.spp, ref.depth), "kernel": c.last_kernel(),
            "paths": int(st["paths"]), "gpu_seconds": round(t_gpu, 2), "oracle_seconds": round(t_cpu, 1),
            "oracle_threads": int(os.environ.get("OMP_NUM_THREADS", "0")) or os.cpu_count(),
            "segments_gpu": int(st["segments"]), "segments_oracle": ost["segments"],
            "pixels": int(diff.size), "pixels_beyond_1e-9": int(len(bad)), "largest_difference": float(diff.max()),
            "rmse_rel": float(oracle.rmse_rel(img, oimg))}
-    ref.region = (0, 0, a.size - 1, a.size - 1)
+    ref.region = (0, 0, H - 1, W - 1)
+    O = oracle.Oracle(ref, seed=13)
     proven = unexplained = 0
     pick = bad[np.random.default_rng(13).permutation(len(bad))[: a.prove]] if len(bad) else np.zeros((0, 2), dtype=np.int64)
     if len(pick):
-        dev = torch.zeros((a.size, a.size, 3), dtype=torch.float64, device="cuda")
+        dev = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
         by_row = {}
         for y, x in pick:
             by_row.setdefault(int(y), []).append(int(x))
