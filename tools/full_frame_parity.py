@@ -5,7 +5,7 @@ put through the proof the parity tests use: every sample of the pixel is rendere
 and re-traced by the oracle, and where the two differ the oracle's path must contain a closest-hit
 search whose two best candidates are within 1e-10 of each other (a tie).  Prints one JSON line.
 
-    python tools/full_config_cbox.py [--spp 256] [--size 1024] [--prove 40] [--conf config/mis.conf --width 768 --height 512]
+    python tools/full_frame_parity.py [--spp 256] [--size 1024] [--prove 40] [--conf config/mis.conf --width 768 --height 512]
 """
 import argparse
 import json
