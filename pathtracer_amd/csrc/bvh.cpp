@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <queue>
+#include <utility>
 
 namespace ptx
 {
@@ -333,6 +335,48 @@ struct Collapser
     }
 };
 
+// Renumbers the nodes so that the ones a ray is most likely to visit come first: starting at the
+// root, the node with the largest box (the chance that a random line meets a convex box grows with
+// its surface area) is taken next, `hot` times; the other nodes follow in their depth-first order.
+// The tracers keep the first nodes in LDS, so the low ids should be the busy ones.
+constexpr int HOT_NODES = 4096;
+void hot_nodes_first(std::vector<BvhNode> &nodes, int hot)
+{
+    const int n = static_cast<int>(nodes.size());
+    if (n <= 2)
+        return;
+    auto child_area = [&](const BvhNode &nd, int j) {
+        const double e0 = double(nd.hi[0][j]) - nd.lo[0][j], e1 = double(nd.hi[1][j]) - nd.lo[1][j], e2 = double(nd.hi[2][j]) - nd.lo[2][j];
+        return e0 * e1 + e1 * e2 + e2 * e0;
+    };
+    std::vector<int32_t> new_id(n, -1);
+    std::priority_queue<std::pair<double, int32_t>> open; // (area, old id); equal areas: the higher old id first, any fixed rule will do
+    open.push({std::numeric_limits<double>::infinity(), 0});
+    int next = 0;
+    while (!open.empty() && next < hot)
+    {
+        const int32_t me = open.top().second;
+        open.pop();
+        new_id[me] = next++;
+        for (int j = 0; j < 4; j++)
+            if (nodes[me].child[j] >= 0)
+                open.push({child_area(nodes[me], j), nodes[me].child[j]});
+    }
+    for (int i = 0; i < n; i++)
+        if (new_id[i] < 0)
+            new_id[i] = next++;
+    std::vector<BvhNode> out(n);
+    for (int i = 0; i < n; i++)
+    {
+        BvhNode nd = nodes[i];
+        for (int j = 0; j < 4; j++)
+            if (nd.child[j] >= 0)
+                nd.child[j] = new_id[nd.child[j]];
+        out[new_id[i]] = nd;
+    }
+    nodes.swap(out);
+}
+
 } // namespace
 
 void build_bvh(const float *verts, int n_tris, Bvh &out, bool median)
@@ -390,6 +434,7 @@ void build_bvh(const float *verts, int n_tris, Bvh &out, bool median)
         C.collapse(top, 2, 0, need);
     }
     out.nodes = std::move(C.out);
+    hot_nodes_first(out.nodes, HOT_NODES);
     out.tri_order = std::move(B.order);
     out.max_depth = C.max_depth;
     out.stack_need = need;

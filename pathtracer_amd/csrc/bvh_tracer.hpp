@@ -127,6 +127,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
             lds_lights[k] = S.lights[k];
     }
     int *stk = dyn_stack + threadIdx.x;
+    stage_hot_nodes(S);
     __syncthreads(); // the only barrier: from here on the waves of the workgroup are independent
     const int g = global_wave(), lane = lane_id();
     if (g >= st.n_waves)

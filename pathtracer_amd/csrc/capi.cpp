@@ -415,10 +415,18 @@ int ptx_context_set_option(ptx_context *c, const char *name, int64_t value)
         c->ctx->default_batch_paths = value;
     else if (n == "lds_stack_levels" && value >= 0 && value <= 96)
         c->ctx->lds_stack_levels = static_cast<int>(value);
+    else if (n == "lds_nodes" && value >= -1 && value <= (1 << 20))
+        c->ctx->lds_nodes = static_cast<int>(value);
     else if (n == "bvh_rings" && (value == 0 || value == 1))
         c->ctx->bvh_rings = value != 0;
     else if (n == "ring_batch" && value >= 1 && value <= 64)
         c->ctx->ring_batch = static_cast<int>(value);
+    else if (n == "bvh_wavefront" && (value == 0 || value == 1))
+        c->ctx->bvh_wavefront = value != 0;
+    else if (n == "wf_refill" && value >= 1 && value <= 64)
+        c->ctx->wf_refill = static_cast<int>(value);
+    else if (n == "raycast_wavefront" && (value == 0 || value == 1))
+        c->ctx->raycast_wavefront = value != 0;
     else if (n == "shadow_queue" && (value == 0 || value == 1))
         c->ctx->shadow_queue = value != 0;
     else if (n == "trace_blocks_per_cu" && value >= 0 && value <= 64)

@@ -87,6 +87,7 @@ struct StateNeeds
     size_t ring_bytes = 0; // per wave (ring tracer)
     int spill_levels = 0;  // traversal stack levels kept in global memory, per lane
     int ring_batch = 40;   // ring tracer: lanes per hand-over
+    bool wavefront = false; // wavefront tracer: two ray queues, records and end states by path id instead of record slots
 };
 
 // State region of ptx_render_static: device memory the library owns from load to unload, one
@@ -97,12 +98,28 @@ constexpr size_t STATIC_STATE_BYTES = size_t(256) << 20;
 static __device__ __align__(256) unsigned char scratch[STATIC_STATE_BYTES];
 
 // per-precision device tables + per-batch path state
+// device-side pieces of one wavefront queue carved out of a buffer
+template <class R> static size_t wf_queue_bytes(int64_t cap) { return static_cast<size_t>(cap) * (7 * sizeof(R) + 8) + 256; }
+template <class R> static WfQueue<R> wf_queue_at(char *base, int64_t cap)
+{
+    WfQueue<R> q;
+    q.cap = cap;
+    q.count = reinterpret_cast<uint32_t *>(base);
+    q.pool = q.count + 1;
+    R *f = reinterpret_cast<R *>(base + 256);
+    q.o = f, q.d = f + 3 * cap, q.t = f + 6 * cap;
+    q.pid = reinterpret_cast<uint32_t *>(f + 7 * cap);
+    q.tri = reinterpret_cast<int32_t *>(q.pid + cap);
+    return q;
+}
 template <class R> struct Context::Impl
 {
     DeviceBuffer tri_pre, mats, lights, tri_nrm;
     DeviceBuffer bvh; // triangle records of the 4-wide BVH
     DeviceBuffer state_mem; // one slab carved into the arrays of a render call (layout_state)
     DState<R> st;
+    WfQueue<R> wfq[2]; // wavefront tracer: the two ray queues ...
+    WfState<R> wfs;    // ... and the per-path records and end states
     bool ready = false;
 
     void build_tables(const Scene &sc, const Bvh &bvh, bool brute, hipStream_t s)
@@ -261,8 +278,22 @@ template <class R> struct Context::Impl
             return base ? base + off : nullptr;
         };
         const size_t N = static_cast<size_t>(n.paths);
-        st.records = reinterpret_cast<R *>(take(static_cast<size_t>(n.waves) * n.slots * n.depth * REC_STRIDE * sizeof(R)));
+        st.records = n.wavefront ? nullptr : reinterpret_cast<R *>(take(static_cast<size_t>(n.waves) * n.slots * n.depth * REC_STRIDE * sizeof(R)));
         st.result = reinterpret_cast<R *>(take(N * 3 * sizeof(R)));
+        if (n.wavefront)
+        {
+            for (int q = 0; q < 2; q++)
+            {
+                char *at = take(wf_queue_bytes<R>(n.paths));
+                if (base)
+                    wfq[q] = wf_queue_at<R>(at, n.paths);
+            }
+            wfs.rec = reinterpret_cast<R *>(take(N * 6 * static_cast<size_t>(n.depth) * sizeof(R)));
+            wfs.fin = reinterpret_cast<uint32_t *>(take(N * sizeof(uint32_t)));
+            wfs.result = st.result;
+            wfs.N = n.paths;
+            wfs.rows = std::max(n.waves, 1);
+        }
         st.wave_stats = reinterpret_cast<unsigned long long *>(take(static_cast<size_t>(n.waves) * WAVE_STATS * sizeof(unsigned long long)));
         st.stats = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * 8));
         st.pool = reinterpret_cast<unsigned int *>(take(sizeof(unsigned int)));
@@ -272,6 +303,8 @@ template <class R> struct Context::Impl
         st.n_waves = 0;
         st.slots = n.slots;
         st.ring_batch = n.ring_batch;
+        if (n.wavefront)
+            wfs.wave_stats = st.wave_stats;
         return total;
     }
 
@@ -520,7 +553,7 @@ template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::
     S.bvh_tris = static_cast<const uint4 *>(bvh);
     S.n_nodes = g.n_nodes, S.id_bits = g.id_bits;
     S.stack_levels = g.stack_need; // the operator kernels keep the whole stack in LDS
-    S.sq_light = -1, S.pad3_ = 0;
+    S.sq_light = -1, S.lds_nodes = 0;
     for (size_t l = 0; l < sc.lights.size() && S.sq_light < 0; l++)
         if (sc.lights[l].type == 0)
             S.sq_light = static_cast<int>(l);
@@ -562,6 +595,122 @@ void Context::generate_rays(double *ro, double *rd)
     HIP_CHECK(hipStreamSynchronize(s));
 }
 
+// Occupancy and LDS split of a kernel that traverses the BVH.  The registers (and the static LDS)
+// allow `by_regs` workgroups per CU.  The dynamic LDS of a workgroup holds its traversal stacks
+// (1 KB per level; deeper levels spill to global memory) and, behind them, a copy of the first
+// nodes of the tree (the builder numbers the busiest nodes first).  The occupancy is what the
+// registers allow as long as that leaves a useful amount of LDS per workgroup; lds_stack_cap and
+// lds_nodes_opt (options for tests and tuning) force the split.
+struct BvhLdsPlan
+{
+    int per_cu = 1, levels = 0, nodes = 0;
+    size_t dyn_bytes = 0;
+};
+static BvhLdsPlan plan_bvh_lds(const void *kernel, int want_per_cu, int stack_need, int lds_stack_cap, int n_nodes, int lds_nodes_opt)
+{
+    BvhLdsPlan r;
+    hipFuncAttributes fa;
+    HIP_CHECK(hipFuncGetAttributes(&fa, kernel));
+    int dev = 0, lds_cu = 0, by_regs = 1;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev));
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&by_regs, kernel, BLOCK, 0));
+    if (want_per_cu > 0)
+        by_regs = std::min(by_regs, want_per_cu);
+    // below about 24 levels in LDS (16 next to cached nodes) the spills stop being the exception
+    const int cap = lds_stack_cap > 0 ? std::min(lds_stack_cap, stack_need) : stack_need;
+    const int useful = std::min(cap, lds_nodes_opt != 0 ? 16 : 24);
+    const int level_bytes = BLOCK * 4;
+    int avail = 0;
+    for (int b = std::max(by_regs, 1); b >= 1; b--)
+    {
+        // LDS is handed out in granules of 1280 bytes on this device, which the calculator
+        // does not round to (measured: 3 x 54272 bytes do not fit 160 KB, 3 x 53760 do)
+        const int granule = 1280;
+        int dyn = (lds_cu / b) / granule * granule - static_cast<int>(fa.sharedSizeBytes);
+        dyn = std::min(dyn, cap * level_bytes + std::max(n_nodes, 0) * 64) / 64 * 64;
+        int got = 0;
+        while (dyn >= useful * level_bytes)
+        {
+            HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, kernel, BLOCK, static_cast<size_t>(dyn)));
+            if (got >= b)
+                break;
+            got = 0;
+            dyn -= granule;
+        }
+        if (dyn >= useful * level_bytes && got >= b)
+        {
+            avail = dyn, r.per_cu = b;
+            break;
+        }
+    }
+    if (avail <= 0)
+        avail = std::min(cap, std::max(1, (lds_cu - static_cast<int>(fa.sharedSizeBytes)) / level_bytes)) * level_bytes; // one workgroup per CU
+    int levels = std::min(cap, avail / level_bytes);
+    int nodes = 0;
+    if (lds_nodes_opt != 0)
+    {
+        // with nodes in LDS the stacks keep 16 levels unless the option says otherwise
+        const int keep = std::min(levels, lds_stack_cap > 0 ? cap : 16);
+        nodes = std::min((avail - keep * level_bytes) / 64, n_nodes);
+        if (lds_nodes_opt > 0)
+            nodes = std::min(nodes, lds_nodes_opt);
+        if (nodes >= 16)
+            levels = keep;
+        else
+            nodes = 0;
+    }
+    r.levels = levels, r.nodes = nodes;
+    r.dyn_bytes = static_cast<size_t>(levels) * level_bytes + static_cast<size_t>(nodes) * 64;
+    HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(r.dyn_bytes)));
+    return r;
+}
+
+template <class R> static auto wf_traverse_kernel()
+{
+    if constexpr (sizeof(R) == 8)
+        return k_wf_traverse_f64<0>;
+    else
+        return k_wf_traverse_f32<0>;
+}
+
+// closest hits of n rays through the wavefront tracer's traversal kernel (timing aid)
+template <class R> void Context::raycast_wavefront_impl(Impl<R> &im, const double *ro, const double *rd, int64_t n, int32_t *ids, double *pts)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    auto S = make_dscene<R>(scene_, *geo_, im.tri_pre.p, im.mats.p, im.lights.p, im.tri_nrm.p, im.bvh.p, brute_);
+    auto kernel = wf_traverse_kernel<R>();
+    const BvhLdsPlan lp = plan_bvh_lds(reinterpret_cast<const void *>(kernel), trace_blocks_per_cu, geo_->stack_need, lds_stack_levels, S.n_nodes, lds_nodes);
+    const int grid = lp.per_cu * n_cus_;
+    DeviceBuffer d_o, d_d, d_ids, d_pts, d_q, d_spill, d_stats;
+    d_o.alloc(n * 24), d_d.alloc(n * 24), d_ids.alloc(n * 4);
+    if (pts)
+        d_pts.alloc(n * 24);
+    d_q.alloc(wf_queue_bytes<R>(n));
+    const int spill_levels = std::max(geo_->stack_need - lp.levels, 0);
+    d_spill.alloc(static_cast<size_t>(spill_levels) * grid * BLOCK * 4);
+    d_stats.alloc(static_cast<size_t>(grid) * (BLOCK / 64) * WAVE_STATS * 8);
+    HIP_CHECK(hipMemsetAsync(d_stats.p, 0, d_stats.bytes, s));
+    HIP_CHECK(hipMemcpyAsync(d_o.p, ro, n * 24, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(d_d.p, rd, n * 24, hipMemcpyHostToDevice, s));
+    WfQueue<R> Q = wf_queue_at<R>(static_cast<char *>(d_q.p), n);
+    S.stack_levels = lp.levels, S.lds_nodes = lp.nodes;
+    S.spill = static_cast<uint32_t *>(d_spill.p), S.spill_stride = grid * BLOCK;
+    if (std::getenv("PTX_DEBUG"))
+        std::fprintf(stderr, "[ptx] wavefront traversal: %d workgroups per CU, %zu bytes of dynamic LDS (%d of %d stack levels, %d nodes)\n", lp.per_cu,
+                     lp.dyn_bytes, lp.levels, geo_->stack_need, lp.nodes);
+    hipLaunchKernelGGL((k_wf_rays_in<R>), dim3(blocks_for(n)), dim3(BLOCK), 0, s, static_cast<const double *>(d_o.p), static_cast<const double *>(d_d.p), n, Q);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lp.dyn_bytes, s, S, Q, wf_refill, static_cast<unsigned long long *>(d_stats.p));
+    hipLaunchKernelGGL((k_wf_hits_out<R>), dim3(blocks_for(n)), dim3(BLOCK), 0, s, S, Q, n, static_cast<int32_t *>(d_ids.p),
+                       pts ? static_cast<double *>(d_pts.p) : nullptr);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(ids, d_ids.p, n * 4, hipMemcpyDeviceToHost, s));
+    if (pts)
+        HIP_CHECK(hipMemcpyAsync(pts, d_pts.p, n * 24, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
 void Context::raycast(const double *ro, const double *rd, int64_t n, int32_t *ids, double *pts, bool from_camera, int mode)
 {
     require_scene();
@@ -571,6 +720,14 @@ void Context::raycast(const double *ro, const double *rd, int64_t n, int32_t *id
         n = static_cast<int64_t>(scene_.width) * scene_.height;
     if (n <= 0)
         return;
+    if (raycast_wavefront && !brute_ && !from_camera)
+    {
+        if (mode == PTX_MODE_F64_)
+            raycast_wavefront_impl<double>(*f64_, ro, rd, n, ids, pts);
+        else
+            raycast_wavefront_impl<float>(*f32_, ro, rd, n, ids, pts);
+        return;
+    }
     DeviceBuffer d_o, d_d, d_ids, d_pts;
     if (!from_camera)
     {
@@ -653,13 +810,16 @@ template <class R> struct TracePlan
     int blocks_per_cu = 1;
     size_t dyn_lds = 0; // bytes of traversal stacks per workgroup (BVH kernels)
     int stack_levels = 0; // levels of them
+    int lds_nodes = 0;    // node records kept in LDS behind the stack levels
     bool rings = false;   // the ring tracer (needs DState::rings)
     bool ring_tests = false; // ... compiled with visibility tests (a longer ray ring)
+    bool wavefront = false;  // the wavefront tracer: `traverse` instead of `kernel`, shading in kernels of its own
+    void (*traverse)(DScene<R>, WfQueue<R>, int, unsigned long long *) = nullptr;
 };
 
 template <class R, bool BRUTE>
 static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shadow_queue, int stack_need, int lds_stack_cap, bool rings = false,
-                               bool fast = false)
+                               bool fast = false, int lds_nodes_opt = -1, bool wavefront = false)
 {
     TracePlan<R> p;
     const bool tab = S.n_mats <= LDS_MATS && S.n_lights <= LDS_LIGHTS;
@@ -741,59 +901,31 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
         std::snprintf(nm, sizeof(nm), "k_trace_rings_%s<%s, %s>", sizeof(R) == 8 ? "f64" : "f32", tab ? "true" : "false", sq ? "true" : "false");
         p.name = nm;
     }
-    // BVH kernels: how many stack levels to keep in LDS.  The registers (and the static LDS)
-    // allow `by_regs` workgroups per CU; the stacks get what is left of the CU's LDS at that
-    // occupancy, as long as that is a useful depth, and deeper levels spill to global memory.
+    // BVH scenes whose lights need no visibility test (the reference's estimator without square
+    // lights): traversal and shading in separate kernels, segments through two ray queues
+    if (!BRUTE && !fast && S.n_square == 0 && wavefront)
+    {
+        p.wavefront = true, p.rings = false, p.ring_tests = false;
+        p.traverse = wf_traverse_kernel<R>();
+        p.name = sizeof(R) == 8 ? "k_wf_traverse_f64<0>" : "k_wf_traverse_f32<0>";
+    }
+    // BVH kernels: occupancy and the split of the dynamic LDS between stack levels and node records
     int per_cu = blocks_per_cu;
     p.stack_levels = 0;
     if (!BRUTE)
     {
-        hipFuncAttributes fa;
-        HIP_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(p.kernel)));
-        int dev = 0, lds_cu = 0, by_regs = 1;
-        HIP_CHECK(hipGetDevice(&dev));
-        HIP_CHECK(hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev));
-        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&by_regs, p.kernel, BLOCK, 0));
-        if (per_cu > 0)
-            by_regs = std::min(by_regs, per_cu);
-        // below about 24 levels in LDS the spills stop being the exception; lds_stack_cap (an
-        // option for tests and tuning) forces a smaller LDS stack
-        const int cap = lds_stack_cap > 0 ? std::min(lds_stack_cap, stack_need) : stack_need;
-        const int useful = std::min(cap, 24);
-        int levels = cap;
-        per_cu = 1;
-        for (int b = std::max(by_regs, 1); b >= 1; b--)
-        {
-            const int avail = lds_cu / b - static_cast<int>(fa.sharedSizeBytes);
-            int lv = std::min(cap, avail / (BLOCK * 4));
-            int got = 0;
-            while (lv >= useful)
-            {
-                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, p.kernel, BLOCK, static_cast<size_t>(lv) * BLOCK * 4));
-                // LDS is handed out in granules of 1280 bytes on this device, which the calculator
-                // does not round to (measured: 3 x 54272 bytes do not fit 160 KB, 3 x 53760 do)
-                const int granule = 1280;
-                const int per_block = (static_cast<int>(fa.sharedSizeBytes) + lv * BLOCK * 4 + granule - 1) / granule * granule;
-                if (got >= b && per_block * b <= lds_cu)
-                    break;
-                got = 0;
-                lv--;
-            }
-            if (lv >= useful && got >= b)
-            {
-                levels = lv, per_cu = b;
-                break;
-            }
-        }
-        p.stack_levels = levels;
-        p.dyn_lds = static_cast<size_t>(levels) * BLOCK * 4;
-        allow_dynamic_lds(p.kernel, p.dyn_lds);
+        const void *kfn = p.wavefront ? reinterpret_cast<const void *>(p.traverse) : reinterpret_cast<const void *>(p.kernel);
+        const BvhLdsPlan lp = plan_bvh_lds(kfn, blocks_per_cu, stack_need, lds_stack_cap, S.n_nodes, lds_nodes_opt);
+        per_cu = lp.per_cu;
+        p.stack_levels = lp.levels;
+        p.lds_nodes = lp.nodes;
+        p.dyn_lds = lp.dyn_bytes;
     }
     else if (per_cu <= 0)
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, p.kernel, BLOCK, 0));
     if (std::getenv("PTX_DEBUG"))
-        std::fprintf(stderr, "[ptx] trace kernel: %d workgroups per CU, %zu bytes of dynamic LDS (%d of %d stack levels)\n", per_cu,
-                     p.dyn_lds, p.stack_levels, stack_need);
+        std::fprintf(stderr, "[ptx] trace kernel: %d workgroups per CU, %zu bytes of dynamic LDS (%d of %d stack levels, %d of %d nodes)\n", per_cu,
+                     p.dyn_lds, p.stack_levels, stack_need, p.lds_nodes, S.n_nodes);
     p.blocks_per_cu = std::max(per_cu, 1);
     return p;
 }
@@ -807,6 +939,34 @@ static void launch_trace(const TracePlan<R> &plan, const DScene<R> &S, const DCa
     const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(grid_blocks, (B.n_paths + BLOCK - 1) / BLOCK));
     st.n_waves = static_cast<int>(blocks) * (BLOCK / 64);
     hipLaunchKernelGGL(plan.kernel, dim3(static_cast<unsigned>(blocks)), dim3(BLOCK), plan.dyn_lds, s, S, cam, B, st, chunk);
+    HIP_CHECK(hipGetLastError());
+}
+
+// One batch through the wavefront tracer: camera rays, then per bounce one persistent traversal
+// launch and one shading launch (which reads the count the launch before it produced: nothing
+// comes back to the host), then the fold of the records.  grid_blocks: workgroups of the
+// traversal kernel (the spill columns and the statistics rows were laid out for them).
+template <class R>
+static void launch_wavefront(const TracePlan<R> &plan, const DScene<R> &S, const DCamera &cam, const DBatch &B, Context::Impl<R> &im, hipStream_t s,
+                             int grid_blocks, int refill)
+{
+    DState<R> &st = im.st;
+    st.n_waves = grid_blocks * (BLOCK / 64);
+    const unsigned per_path = blocks_for(B.n_paths);
+    HIP_CHECK(hipMemsetAsync(st.wave_stats, 0, static_cast<size_t>(st.n_waves) * WAVE_STATS * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL((k_wf_camera<R>), dim3(per_path), dim3(BLOCK), 0, s, cam, B, im.wfq[0]);
+    for (int b = 0; b < B.depth; b++)
+    {
+        const WfQueue<R> &in = im.wfq[b & 1], &out = im.wfq[(b + 1) & 1];
+        if (b == 0)
+            hipLaunchKernelGGL((k_wf_counts<R>), dim3(1), dim3(1), 0, s, in, static_cast<uint32_t>(B.n_paths), out);
+        else
+            HIP_CHECK(hipMemsetAsync(out.count, 0, 8, s)); // count and pool of the queue this bounce fills
+        hipLaunchKernelGGL(plan.traverse, dim3(static_cast<unsigned>(grid_blocks)), dim3(BLOCK), plan.dyn_lds, s, S, in, refill, st.wave_stats);
+        hipLaunchKernelGGL((k_wf_shade<R>), dim3(static_cast<unsigned>((B.n_paths + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK)), dim3(WF_SHADE_BLOCK), 0, s, S, B,
+                           in, out, im.wfs, b);
+    }
+    hipLaunchKernelGGL((k_wf_resolve<R>), dim3(per_path), dim3(BLOCK), 0, s, S, B, im.wfs);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -906,7 +1066,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     // The grid of the tracer is just large enough to fill the device: its waves are persistent.
     const bool fast = o.estimator == PTX_ESTIMATOR_FAST_;
     const TracePlan<R> plan = brute_ ? plan_trace<R, true>(S, trace_blocks_per_cu, shadow_queue, 0, 0, false, fast)
-                                    : plan_trace<R, false>(S, trace_blocks_per_cu, shadow_queue, geo_->stack_need, lds_stack_levels, bvh_rings, fast);
+                                    : plan_trace<R, false>(S, trace_blocks_per_cu, shadow_queue, geo_->stack_need, lds_stack_levels, bvh_rings, fast, lds_nodes, bvh_wavefront);
     last_kernel_ = plan.name;
 
     // ---- size the batch and the grid so that the state fits the memory there is --------------
@@ -937,6 +1097,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
         need.paths = cap, need.depth = depth;
         need.waves = grid_blocks * (BLOCK / 64);
         need.slots = plan.rings ? RING_SLOTS : LANE_SLOTS;
+        need.wavefront = plan.wavefront;
         need.ring_bytes = plan.rings ? ring_bytes<R>(fast, plan.ring_tests) : 0;
         need.spill_levels = brute_ ? 0 : std::max(geo_->stack_need - plan.stack_levels, 0);
         need.ring_batch = ring_batch;
@@ -965,6 +1126,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     {
         // stack levels the LDS does not hold: one column per lane of the launch in global memory
         S.stack_levels = plan.stack_levels;
+        S.lds_nodes = plan.lds_nodes;
         S.spill = spill;
         S.spill_stride = need.waves * 64;
     }
@@ -992,7 +1154,10 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
             B.n_paths = B.n_pix * B.n_samples;
             if (tm)
                 tm->mark(s, RenderTimers::TRACE);
-            launch_trace<R>(plan, S, cam, B, im.st, s, chunk, grid_blocks);
+            if (plan.wavefront)
+                launch_wavefront<R>(plan, S, cam, B, im, s, grid_blocks, wf_refill);
+            else
+                launch_trace<R>(plan, S, cam, B, im.st, s, chunk, grid_blocks);
             launch_finish<R>(S, B, im.st, d_sum, s, tm);
             passes++;
         }

@@ -97,17 +97,28 @@ public:
     // BVH tracer: at most this many traversal stack levels in LDS, deeper ones spill to global memory
     // (0: as many as fit at full occupancy)
     int lds_stack_levels = 0;
+    // BVH tracer: at most this many node records (the first ones: the builder numbers the busiest
+    // nodes first) in LDS behind the stack levels (-1: what fits next to 16 stack levels; 0: none)
+    int lds_nodes = -1;
     // BVH scenes with at most 12 square lights: the tracer that queues hits and rays per wave (ring tracer)
     // instead of the one that keeps every path on its lane
     bool bvh_rings = true;
     // ring tracer: lanes that hand over hits / take rays together (1..64)
     int ring_batch = 40;
+    // BVH scenes without square lights, the reference's estimator: traversal and shading in separate
+    // kernels (five waves per SIMD traverse instead of three) with the segments in two ray queues
+    bool bvh_wavefront = true;
+    // wavefront tracer: a wave of the traversal kernel fetches new rays when this many lanes are idle (1..64)
+    int wf_refill = 24;
+    // timing aid: ptx_raycast through the wavefront tracer's traversal kernel (unit-length directions)
+    bool raycast_wavefront = false;
 
     struct Geometry;
     template <class R> struct Impl;
 
 private:
     void require_scene() const;
+    template <class R> void raycast_wavefront_impl(Impl<R> &im, const double *ro, const double *rd, int64_t n, int32_t *ids, double *pts);
     template <class R> void render_impl(Impl<R> &im, const RenderOpts &o, double *d_sum, RenderStats &stats, bool static_state);
 
     int device_;

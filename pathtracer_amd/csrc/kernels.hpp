@@ -50,7 +50,8 @@ template <class R> struct DScene
     const uint4 *bvh_nodes;    // [n_nodes][4] 64-byte nodes of the 4-wide BVH (child boxes quantised to 8 bits)
     const uint4 *bvh_tris;     // [n_tris][3] triangle records in intersector order: the nine float coordinates, face id
     int n_nodes, id_bits;      // id_bits: bits of a stack entry that hold the record id
-    int sq_light, pad3_;       // index of the first square light (-1: none)
+    int sq_light;              // index of the first square light (-1: none)
+    int lds_nodes;             // the first lds_nodes node records are also in LDS, behind the stack levels (tracers only)
     int stack_levels;          // traversal stack levels held in LDS; deeper levels go to `spill`
     int spill_stride;          // lanes of the launch
     uint32_t *spill;           // [levels beyond stack_levels][spill_stride] (null when the LDS stack holds the whole bound)
@@ -361,6 +362,17 @@ constexpr int TRI_REC_Q = 3; // 16-byte words of a triangle record
 // compiler merges the two stores of a push into one flat store behind a pointer select.
 typedef __attribute__((address_space(3))) int lds_int_t;
 typedef __attribute__((address_space(1))) uint32_t global_u32_t;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4_t lds_u32x4_t;
+
+// copies the first S.lds_nodes node records behind the workgroup's stack levels (all threads; the
+// caller's barrier follows)
+template <class R> __device__ __forceinline__ void stage_hot_nodes(const DScene<R> &S)
+{
+    uint4 *dst = reinterpret_cast<uint4 *>(dyn_stack + S.stack_levels * BLOCK);
+    for (int k = threadIdx.x; k < S.lds_nodes * 4; k += BLOCK)
+        dst[k] = S.bvh_nodes[k];
+}
 
 // One record visit.  ANY = false: closest hit (winner = smallest distance beyond self_eps, ties ->
 // lowest face id; T.target = triangle, o + T.best_t * d = point).  ANY = true: is the segment of length T.best
@@ -409,8 +421,20 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
         visits[0]++;
         // 64-byte node: corner and cell size of the 8-bit grid its child boxes are quantised to,
         // six words of grid coordinates (low and high plane per axis, one byte per child), four ids
-        const uint4 *rec = S.bvh_nodes + (size_t)T.cur * 4;
-        const uint4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+        // the busiest nodes (lowest ids) come from the workgroup's LDS copy: a compute unit's vector
+        // cache serves about one scattered 16-byte lane access per cycle, and the top of the tree is
+        // a third of all node visits
+        u32x4_t n0, n1, n2, n3;
+        if (T.cur < S.lds_nodes)
+        {
+            const lds_u32x4_t *rec = (const lds_u32x4_t *)(dyn_stack + S.stack_levels * BLOCK) + T.cur * 4;
+            n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+        }
+        else
+        {
+            const u32x4_t *rec = reinterpret_cast<const u32x4_t *>(S.bvh_nodes) + (size_t)T.cur * 4;
+            n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+        }
         const float tmaxf = float(T.best) * (1.0f + K) + 1e-30f;
         // plane distance t = A * q + B per axis, A = cell * slope, B = (corner - origin) * slope, with
         // the origin end and the plane (low or high) that make a near plane nearer and a far plane
@@ -861,6 +885,8 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             lds_tmat[k] = S.tri_mat[k];
     }
     int *stk = intersector_scratch<R, BRUTE>(S, BRUTE ? lds_raw : dyn_stack);
+    if constexpr (!BRUTE)
+        stage_hot_nodes(S);
     __syncthreads(); // the only barrier: from here on the waves of the workgroup are independent
     const int g = global_wave(), lane = lane_id();
     if (g >= st.n_waves)
@@ -1527,6 +1553,7 @@ __global__ void __launch_bounds__(BLOCK, 3) k_trace_fast_f32(DScene<float> S, DC
 
 } // namespace ptx
 #include "bvh_tracer.hpp"
+#include "wavefront.hpp"
 namespace ptx
 {
 

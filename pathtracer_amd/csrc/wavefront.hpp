@@ -1,0 +1,392 @@
+// Wavefront tracer of BVH scenes without square lights: traversal and shading are separate
+// kernels.  Included by kernels.hpp.
+//
+// The closest-hit traversal of a BVH scene waits for one dependent record fetch per step, and what
+// hides that wait is the number of waves a SIMD holds.  Traversal alone needs about 90 vector
+// registers in double precision -- five waves per SIMD -- while a kernel that also shades needs
+// 168 (three).  So the segments of a batch of paths go through memory between two kernels:
+//
+//   k_wf_camera    one thread per path of the batch: the camera ray -> ray queue
+//   k_wf_traverse  persistent waves; a lane takes the next ray of the queue whenever its traversal
+//                  is complete (one atomic add per refill of a wave) and writes (t, triangle)
+//   k_wf_shade     one thread per ray of the queue: termination rules, shading normal, light
+//                  sampling, next direction (cPathTracer.cpp:598-673 of the reference); writes the
+//                  bounce record and, compacted per wave, the continuation ray -> the other queue
+//   k_wf_resolve   one thread per path: back-to-front fold of its records (cPathTracer.cpp:679-689)
+//
+// A queue entry is (path id, origin, direction); the hit comes back in (t, triangle) at the same
+// index.  Queue counts stay on the device: a launch reads the count the previous one produced.
+#pragma once
+
+namespace ptx
+{
+
+// one ray queue (structure of arrays over `cap` entries) and the hits of its rays
+template <class R> struct WfQueue
+{
+    R *o, *d;          // [3][cap]
+    uint32_t *pid;     // [cap] path id within the batch
+    R *t;              // [cap] ray parameter of the closest hit
+    int32_t *tri;      // [cap] intersector-order triangle, -1: miss
+    uint32_t *count;   // rays in the queue
+    uint32_t *pool;    // next ray no lane has taken yet (k_wf_traverse)
+    int64_t cap;
+};
+
+constexpr int WF_CHUNK = 256; // queue entries a wave of the traversal kernel takes per atomic add
+
+// Persistent traversal.  `refill`: a wave fetches new rays when that many of its lanes are idle.
+template <class R> __device__ __forceinline__ void wf_traverse_body(const DScene<R> &S, const WfQueue<R> &Q, int refill, unsigned long long *wave_stats)
+{
+    int *stk = dyn_stack + threadIdx.x;
+    stage_hot_nodes(S);
+    __syncthreads(); // the only barrier
+    const int lane = lane_id(), g = global_wave();
+    const uint32_t n = *Q.count;
+    bool busy = false, drained = false;
+    uint32_t idx = 0;
+    uint32_t next = 0, end = 0; // the wave's current range of queue entries (wave-uniform)
+    Trav<R> T;
+    trav_init(T, V3<R>{R(0), R(0), R(0)}, V3<R>{R(1), R(1), R(1)});
+    V3<R> o = {R(0), R(0), R(0)}, d = {R(0), R(0), R(0)};
+    uint32_t n_visit[2] = {0, 0};
+    const size_t cap = size_t(Q.cap);
+    for (;;)
+    {
+        // ---- idle lanes take the next rays of the queue -----------------------------------------
+        const unsigned long long idle = __ballot(!busy);
+        const uint32_t n_idle = uint32_t(__popcll(idle));
+        if (!drained && n_idle > 0u)
+        {
+            if (next == end)
+            {
+                // the wave's range of queue entries is used up: one atomic add for the next WF_CHUNK
+                uint32_t base = 0;
+                if (lane == 0)
+                    base = atomicAdd(Q.pool, uint32_t(WF_CHUNK));
+                base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+                next = base < n ? base : n;
+                end = n - next < uint32_t(WF_CHUNK) ? n : next + uint32_t(WF_CHUNK);
+            }
+            const uint32_t i = next + rank_in(idle);
+            if (!busy && i < end)
+            {
+                o = {Q.o[i], Q.o[cap + i], Q.o[2 * cap + i]};
+                d = {Q.d[i], Q.d[cap + i], Q.d[2 * cap + i]};
+                trav_init(T, o, d);
+                idx = i, busy = true;
+            }
+            next = end - next < n_idle ? end : next + n_idle;
+            if (next >= n)
+                drained = true; // every ray of the queue has a lane
+        }
+        if (__ballot(busy) == 0ull)
+            break; // nothing left to take (drained, or the queue was empty) and every lane idle
+        // ---- traversal steps until enough lanes are idle again ----------------------------------
+        for (;;)
+        {
+            const int n_trav = __popcll(__ballot(busy));
+            if (n_trav == 0 || (!drained && 64 - n_trav >= refill))
+                break;
+            const bool at_tri = busy && T.cur >= S.n_nodes;
+            const int n_tri = __popcll(__ballot(at_tri));
+            bool more = true;
+            if (n_tri * 2 > (n_trav - n_tri) * 3)
+            {
+                if (at_tri)
+                    more = bvh_step<R, 0, 2>(S, o, d, T, stk, n_visit);
+            }
+            else if (busy && !at_tri)
+                more = bvh_step<R, 0, 1>(S, o, d, T, stk, n_visit);
+            if (!more)
+            {
+                Q.t[idx] = T.best_t, Q.tri[idx] = T.target;
+                busy = false;
+            }
+        }
+    }
+    unsigned long long v0 = n_visit[0], v1 = n_visit[1];
+    for (int off = 32; off > 0; off >>= 1)
+        v0 += __shfl_down(v0, off, 64), v1 += __shfl_down(v1, off, 64);
+    if (lane == 0)
+    {
+        wave_stats[g * WAVE_STATS + 4] += v0;
+        wave_stats[g * WAVE_STATS + 5] += v1;
+    }
+}
+
+template <int UNUSED = 0> __global__ void __launch_bounds__(BLOCK, 5) k_wf_traverse_f64(DScene<double> S, WfQueue<double> Q, int refill, unsigned long long *wave_stats)
+{
+    wf_traverse_body<double>(S, Q, refill, wave_stats);
+}
+template <int UNUSED = 0> __global__ void __launch_bounds__(BLOCK, 8) k_wf_traverse_f32(DScene<float> S, WfQueue<float> Q, int refill, unsigned long long *wave_stats)
+{
+    wf_traverse_body<float>(S, Q, refill, wave_stats);
+}
+
+// per-batch state of the wavefront tracer besides the two queues
+template <class R> struct WfState
+{
+    R *rec;          // [6][depth][N]: direct rgb, coefficient rgb of every bounce record, by path id
+    uint32_t *fin;   // [N] (record count << 16) | (tail material + 1) of the finished path
+    R *result;       // [3][N] resolved per-sample radiance (what k_accumulate reads)
+    unsigned long long *wave_stats; // [rows][WAVE_STATS], added to
+    int64_t N;
+    int rows;
+};
+
+// pixel of a path of the batch and the key of its random numbers
+__device__ __forceinline__ void wf_path_pixel(const DBatch &B, uint32_t pid, int &col, int &row)
+{
+    const uint32_t pix = pid % uint32_t(B.n_pix);
+    const int lr = B.row0 + int(pix / uint32_t(B.n_cols));
+    col = B.col0 + int(pix % uint32_t(B.n_cols));
+    row = local_row_to_image_row(B, lr);
+}
+
+// camera rays of the batch -> queue A (cPathTracer::GenerateRay); thread 0 also sets the counts
+template <class R> __global__ void __launch_bounds__(BLOCK) k_wf_camera(DCamera cam, DBatch B, WfQueue<R> A)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= B.n_paths)
+        return;
+    int col, row;
+    wf_path_pixel(B, uint32_t(i), col, row);
+    V3<R> o, d;
+    primary_ray<R>(cam, col, row, o, d);
+    A.o[i] = o.x, A.o[A.cap + i] = o.y, A.o[2 * A.cap + i] = o.z;
+    A.d[i] = d.x, A.d[A.cap + i] = d.y, A.d[2 * A.cap + i] = d.z;
+    A.pid[i] = uint32_t(i);
+}
+
+// sets the counters of a queue (single thread; between two launches on the stream)
+template <class R> __global__ void k_wf_counts(WfQueue<R> A, uint32_t count_a, WfQueue<R> Bq)
+{
+    *A.count = count_a, *A.pool = 0u;
+    *Bq.count = 0u, *Bq.pool = 0u;
+}
+
+// One segment per thread: the hit of ray i of queue `in` is shaded (termination rules, shading
+// normal, light sampling over all lights in order, next direction: cPathTracer.cpp:598-673,
+// cBxDF::Sample_Li cBxDF.cpp:16-52 of the reference; scenes without square lights, so no
+// visibility test), its record stored, and the continuation ray appended to queue `out`.
+// Workgroups of 1024 threads: the place of a workgroup's continuation rays in the other queue costs
+// ONE atomic add (the counts of its 16 waves are summed in LDS first) -- an add per wave on the one
+// counter took longer than the shading itself.
+constexpr int WF_SHADE_BLOCK = 1024;
+template <class R>
+__global__ void __launch_bounds__(WF_SHADE_BLOCK) k_wf_shade(DScene<R> S, DBatch B, WfQueue<R> in, WfQueue<R> out, WfState<R> W, int bnc)
+{
+    __shared__ uint32_t wave_cont[WF_SHADE_BLOCK / 64]; // continuation rays per wave, then their offsets in the workgroup's range
+    __shared__ uint32_t block_base;
+    __shared__ uint32_t block_stats[3]; // segments, shading iterations (waves), records of this workgroup
+    const uint32_t i = blockIdx.x * WF_SHADE_BLOCK + threadIdx.x;
+    const uint32_t n = *in.count;
+    if (blockIdx.x * WF_SHADE_BLOCK >= n)
+        return; // the whole workgroup is beyond the queue
+    if (threadIdx.x < 3)
+        block_stats[threadIdx.x] = 0u;
+    const bool mine = i < n;
+    const int depth = B.depth;
+    const size_t N = size_t(W.N);
+    bool cont = false;
+    V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
+    uint32_t pid = 0, n_rec = 0;
+    if (mine)
+    {
+        const size_t cap = size_t(in.cap);
+        pid = in.pid[i];
+        const V3<R> o = {in.o[i], in.o[cap + i], in.o[2 * cap + i]};
+        const V3<R> sd = {in.d[i], in.d[cap + i], in.d[2 * cap + i]};
+        const int hit_k = in.tri[i];
+        p = o + in.t[i] * sd;
+        int col, row;
+        wf_path_pixel(B, pid, col, row);
+        const uint64_t key = rng_pixel_key(B.seed, uint32_t(row) * uint32_t(B.image_width) + uint32_t(col));
+        const uint32_t sample = uint32_t(B.sample0) + pid / uint32_t(B.n_pix);
+        bool finished = false;
+        uint32_t fin_state = 0;
+        // ---- termination rules (miss / no material -> tail 0; emitter -> Ka) ----------------------
+        int mat_id = -1;
+        if (hit_k >= 0)
+            mat_id = S.tri_mat[hit_k];
+        const R *m = S.mats + (size_t)(mat_id < 0 ? 0 : mat_id) * MAT_STRIDE;
+        if (mat_id < 0)
+            finished = true, fin_state = uint32_t(bnc) << 16;
+        else if (m[13] != R(0))
+            finished = true, fin_state = (uint32_t(bnc) << 16) | uint32_t(mat_id + 1);
+        else
+        {
+            // ---- shading normal ----------------------------------------------------------------------
+            const V3<R> wo = -sd;
+            const R *__restrict__ fn = S.tri_nrm + (size_t)hit_k * 4;
+            const R fn0 = fn[0], fn1 = fn[1], fn2 = fn[2], fn3 = fn[3];
+            V3<R> nrm = {fn0, fn1, fn2};
+            if (fn3 == R(0))
+            {
+                const int face = S.tri_face[hit_k];
+                const float *__restrict__ vp = S.verts + (size_t)face * 9;
+                const float *__restrict__ np = S.normals + (size_t)face * 9;
+                const Float9 fv = load9(vp), fq = load9(np);
+                V3<R> a = {R(fv.v[0]), R(fv.v[1]), R(fv.v[2])}, b = {R(fv.v[3]), R(fv.v[4]), R(fv.v[5])}, c = {R(fv.v[6]), R(fv.v[7]), R(fv.v[8])};
+                V3<R> w = barycentric(p, a, b, c);
+                V3<R> acc = w.x * V3<R>{R(fq.v[0]), R(fq.v[1]), R(fq.v[2])};
+                acc = acc + w.y * V3<R>{R(fq.v[3]), R(fq.v[4]), R(fq.v[5])};
+                acc = acc + w.z * V3<R>{R(fq.v[6]), R(fq.v[7]), R(fq.v[8])};
+                nrm = fast_normalized(acc);
+            }
+            // ---- light sampling over all lights, in order (sphere lights: never tested) ---------------
+            V3<R> direct = {R(0), R(0), R(0)};
+            for (int l = 0; l < S.n_lights; l++)
+            {
+                const R *L = S.lights + (size_t)l * LIGHT_STRIDE;
+                V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
+                const R x1 = rng_draw<R>(key, sample, bnc, 4 * l + 0);
+                const R x2 = rng_draw<R>(key, sample, bnc, 4 * l + 1);
+                const R pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bnc, 4 * l + 2), ro, rd);
+                if (pdf < R(1e-10))
+                    continue;
+                const R cn = dot(nrm, -rd);
+                if (cn < R(0))
+                    continue;
+                const V3<R> f = bxdf_eval(m, rd, wo, nrm);
+                const R w = cn / pdf;
+                direct = direct + V3<R>{(L[1] * w) * f.x, (L[2] * w) * f.y, (L[3] * w) * f.z};
+            }
+            // ---- next direction and indirect coefficient ---------------------------------------------
+            V3<R> coef = {R(0), R(0), R(0)};
+            if (S.enable_indirect)
+            {
+                const R x1 = rng_draw<R>(key, sample, bnc, 4 * S.n_lights + 0);
+                const R x2 = rng_draw<R>(key, sample, bnc, 4 * S.n_lights + 1);
+                bxdf_sample(m, nrm, wo, x1, x2, wi, coef);
+            }
+            R *rec = W.rec + size_t(bnc) * N + pid;
+            const size_t comp = size_t(depth) * N;
+            rec[0] = direct.x, rec[comp] = direct.y, rec[2 * comp] = direct.z;
+            rec[3 * comp] = coef.x, rec[4 * comp] = coef.y, rec[5 * comp] = coef.z;
+            n_rec = 1;
+            if (S.enable_indirect && bnc + 1 < depth)
+                cont = true;
+            else
+                finished = true, fin_state = uint32_t(bnc + 1) << 16;
+        }
+        if (finished)
+            W.fin[pid] = fin_state;
+    }
+    // ---- continuation rays -> the other queue: compacted per wave, one range per workgroup ---------
+    const unsigned long long cm = __ballot(cont);
+    const unsigned long long mm = __ballot(mine);
+    const unsigned long long rm = __ballot(n_rec != 0u);
+    const int lane = lane_id(), wave = int(threadIdx.x >> 6);
+    __syncthreads(); // block_stats is zero
+    if (lane == 0)
+    {
+        wave_cont[wave] = uint32_t(__popcll(cm));
+        if (mm != 0ull)
+        {
+            // statistics: segments, one 64-lane shading iteration, records
+            atomicAdd(&block_stats[0], uint32_t(__popcll(mm)));
+            atomicAdd(&block_stats[1], 1u);
+            atomicAdd(&block_stats[2], uint32_t(__popcll(rm)));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t total = 0;
+        for (int w = 0; w < WF_SHADE_BLOCK / 64; w++)
+        {
+            const uint32_t c = wave_cont[w];
+            wave_cont[w] = total;
+            total += c;
+        }
+        block_base = total ? atomicAdd(out.count, total) : 0u;
+        unsigned long long *row = W.wave_stats + size_t(blockIdx.x % uint32_t(W.rows)) * WAVE_STATS;
+        atomicAdd(row + 0, (unsigned long long)block_stats[0]);
+        atomicAdd(row + 2, (unsigned long long)block_stats[1]);
+        atomicAdd(row + 3, (unsigned long long)block_stats[2]);
+    }
+    __syncthreads();
+    if (cont)
+    {
+        const size_t r = size_t(block_base) + wave_cont[wave] + rank_in(cm), cap = size_t(out.cap);
+        out.o[r] = p.x, out.o[cap + r] = p.y, out.o[2 * cap + r] = p.z;
+        out.d[r] = wi.x, out.d[cap + r] = wi.y, out.d[2 * cap + r] = wi.z;
+        out.pid[r] = pid;
+    }
+}
+
+// One path per thread: its bounce records folded back to front with the per-bounce max-clamp
+// (cPathTracer.cpp:679-689), the per-sample result stored for k_accumulate.
+template <class R> __global__ void __launch_bounds__(BLOCK) k_wf_resolve(DScene<R> S, DBatch B, WfState<R> W)
+{
+#pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
+    const int64_t pid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (pid >= B.n_paths)
+        return;
+    const size_t N = size_t(W.N);
+    const uint32_t rs = W.fin[pid];
+    const int len = int(rs >> 16), tm = int(rs & 0xffffu);
+    R fr = R(0), fg = R(0), fb = R(0);
+    if (tm)
+    {
+        const R *tmat = S.mats + (size_t)(tm - 1) * MAT_STRIDE;
+        fr = tmat[0], fg = tmat[1], fb = tmat[2];
+    }
+    const size_t comp = size_t(B.depth) * N;
+    for (int i = len - 1; i >= 0; i--)
+    {
+        const R *q = W.rec + size_t(i) * N + size_t(pid);
+        fr = q[0] + q[3 * comp] * fr;
+        fg = q[comp] + q[4 * comp] * fg;
+        fb = q[2 * comp] + q[5 * comp] * fb;
+        R mx = fr;
+        if (fg > mx)
+            mx = fg;
+        if (fb > mx)
+            mx = fb;
+        if (R(0) > mx)
+            mx = R(0);
+        if (mx > R(1))
+        {
+            const R inv = R(1) / mx;
+            fr *= inv, fg *= inv, fb *= inv;
+        }
+    }
+    W.result[pid] = fr, W.result[N + pid] = fg, W.result[2 * N + pid] = fb;
+}
+
+// operator form: rays given as [n][3] doubles -> the queue; hits of the queue -> face ids and points
+template <class R>
+__global__ void __launch_bounds__(BLOCK) k_wf_rays_in(const double *__restrict__ ro, const double *__restrict__ rd, int64_t n, WfQueue<R> Q)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i == 0)
+        *Q.count = uint32_t(n), *Q.pool = 0u;
+    if (i >= n)
+        return;
+    const V3<R> dn = normalized(V3<R>{R(rd[i * 3]), R(rd[i * 3 + 1]), R(rd[i * 3 + 2])});
+    for (int k = 0; k < 3; k++)
+        Q.o[k * Q.cap + i] = R(ro[i * 3 + k]);
+    Q.d[i] = dn.x, Q.d[Q.cap + i] = dn.y, Q.d[2 * Q.cap + i] = dn.z;
+    Q.pid[i] = uint32_t(i);
+}
+template <class R>
+__global__ void __launch_bounds__(BLOCK) k_wf_hits_out(DScene<R> S, WfQueue<R> Q, int64_t n, int32_t *__restrict__ face_ids, double *__restrict__ pts)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    const int k = Q.tri[i];
+    face_ids[i] = k < 0 ? -1 : S.tri_face[k];
+    if (pts)
+    {
+        const double qn = __builtin_nan("");
+        const R t = Q.t[i];
+        for (int c = 0; c < 3; c++)
+            pts[i * 3 + c] = k < 0 ? qn : double(Q.o[c * Q.cap + i] + t * Q.d[c * Q.cap + i]);
+    }
+}
+
+} // namespace ptx

@@ -1,9 +1,10 @@
 """Closest-hit rate of the raycast operator on incoherent rays: rays leave the first-hit points of the
 frame in random directions of the hemisphere that faces the camera (what the second segments of the
-paths look like).  Run under `rocprofv3 --kernel-trace --stats` to read the kernel's own duration; the
-wall time printed here includes the copies of the host arrays the operator takes.
+paths look like).  Run under `rocprofv3 --kernel-trace --output-format csv` to read the kernels' own
+durations (tools/raycast_rate.sh does, and lists them per call); the wall time printed here includes
+the copies of the host arrays the operator takes.
 
-    python tools/raycast_rate.py config/room.conf [--rays 4194304]
+    python tools/raycast_rate.py config/room.conf [--rays 4194304] [--variants "raycast_wavefront=1,wf_refill=24;..."]
 """
 import argparse
 import os
@@ -21,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("conf")
     ap.add_argument("--rays", type=int, default=1 << 22)
+    ap.add_argument("--variants", default="", help="option sets (name=value,...) separated by ';': one context and two calls each")
     a = ap.parse_args()
     s = pt.Scene.load_conf(os.path.join(ROOT, a.conf), root_dir=ROOT, width=1024, height=1024, spp=1)
     c = pt.Context(0)
@@ -35,11 +37,26 @@ def main():
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     flip = np.einsum("ij,ij->i", d, cam - o) < 0
     d[flip] *= -1
+    ref = None
     for rep in range(3):
         t0 = time.time()
-        hit, _ = c.raycast(o, d)
+        hit, hp = c.raycast(o, d)
         dt = time.time() - t0
-        print("%d rays, %.1f ms wall (with copies), %.0f%% hit" % (a.rays, dt * 1e3, 100.0 * (hit >= 0).mean()), flush=True)
+        ref = (hit, hp)
+        print("operator: %d rays, %.1f ms wall (with copies), %.0f%% hit" % (a.rays, dt * 1e3, 100.0 * (hit >= 0).mean()), flush=True)
+    for var in filter(None, a.variants.split(";")):
+        cv = pt.Context(0)
+        for kv in var.split(","):
+            k, v = kv.split("=")
+            cv.set_option(k, int(v))
+        cv.build_accel(s)
+        for rep in range(2):
+            t0 = time.time()
+            hit, hp = cv.raycast(o, d)
+            dt = time.time() - t0
+        same = int((hit != ref[0]).sum())
+        far = float(np.nanmax(np.abs(hp - ref[1]))) if (hit >= 0).any() else 0.0
+        print("%s: %.1f ms wall; %d face ids differ from the operator's, hit points within %.3g" % (var, dt * 1e3, same, far), flush=True)
 
 
 if __name__ == "__main__":
