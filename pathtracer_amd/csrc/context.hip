@@ -903,7 +903,7 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
     }
     // BVH scenes whose lights need no visibility test (the reference's estimator without square
     // lights): traversal and shading in separate kernels, segments through two ray queues
-    if (!BRUTE && !fast && S.n_square == 0 && wavefront)
+    if (!BRUTE && !fast && S.n_square == 0 && wavefront && rings)
     {
         p.wavefront = true, p.rings = false, p.ring_tests = false;
         p.traverse = wf_traverse_kernel<R>();

@@ -13,6 +13,7 @@ from test_gpu_parity import assert_f64_parity as _assert_f64_parity
 
 pytestmark = pytest.mark.gpu
 LAST = {}  # context and oracle of the latest render_both(): what a differing pixel is re-traced with
+TRACER = {}  # options of the BVH tracer under test (set by the bvh_tracer fixture)
 
 
 def assert_f64_parity(img, oimg, st=None, ost=None, depth=15):
@@ -27,6 +28,8 @@ def gpu_scene(ref):
 
 def render_both(ref, **ctx_kw):
     c = pt.Context(0, **ctx_kw)
+    for k, v in TRACER.items():
+        c.set_option(k, v)
     c.build_accel(gpu_scene(ref))
     img, st = c.render(mode="f64", seed=13)
     O = oracle.Oracle(ref, seed=13)
@@ -143,33 +146,49 @@ def test_intersector_hand_over_at_the_record_limit(cbox):
         assert np.array_equal(c.first_hit(), oracle.Oracle(ref).first_hit())
 
 
-# ---- BVH scenes without square lights: the ring tracer (hits and rays queue per wave) -------------
+# ---- BVH scenes without square lights: the ring tracer (hits and rays queue per wave) and the
+# wavefront tracer (traversal and shading in separate kernels) ----------------------------------------
 @pytest.fixture()
 def mis(root):
     return scene_io.load_conf(os.path.join(root, "config/mis.conf"), root_dir=root, width=48, height=32, spp=3)
 
 
+@pytest.fixture(params=["rings", "wavefront"])
+def bvh_tracer(request):
+    TRACER.clear()
+    TRACER.update(bvh_wavefront=int(request.param == "wavefront"))
+    yield request.param
+    TRACER.clear()
+
+
+def assert_tracer(c, bvh_tracer):
+    assert ("k_wf_" in c.last_kernel()) == (bvh_tracer == "wavefront"), c.last_kernel()
+
+
 @pytest.mark.parametrize("depth", [1, 2, 40])
-def test_ring_tracer_extreme_depths(mis, depth):
+def test_ring_tracer_extreme_depths(mis, depth, bvh_tracer):
     ref = copy.deepcopy(mis)
     ref.depth = depth
     img, st, oimg, ost, c = render_both(ref)
     assert not c.accel_info()["brute_force"]
+    assert_tracer(c, bvh_tracer)
     assert_f64_parity(img, oimg, st, ost, depth=depth)
 
 
 @pytest.mark.parametrize("w,h,spp", [(1, 1, 1), (5, 3, 1), (9, 7, 33)])
-def test_ring_tracer_fewer_paths_than_lanes_and_ragged_counts(root, w, h, spp):
+def test_ring_tracer_fewer_paths_than_lanes_and_ragged_counts(root, w, h, spp, bvh_tracer):
     ref = scene_io.load_conf(os.path.join(root, "config/mis.conf"), root_dir=root, width=w, height=h, spp=spp)
-    img, st, oimg, ost, _ = render_both(ref)
+    img, st, oimg, ost, c = render_both(ref)
+    assert_tracer(c, bvh_tracer)
     assert st["paths"] == w * h * spp
     assert_f64_parity(img, oimg, st, ost)
 
 
-def test_ring_tracer_without_lights_and_without_indirect_light(mis):
+def test_ring_tracer_without_lights_and_without_indirect_light(mis, bvh_tracer):
     ref = copy.deepcopy(mis)
     ref.lights = np.zeros((0, 16))
-    img, st, oimg, ost, _ = render_both(ref)
+    img, st, oimg, ost, c = render_both(ref)
+    assert_tracer(c, bvh_tracer)
     assert_f64_parity(img, oimg, st, ost)
     ref = copy.deepcopy(mis)
     ref.enable_indirect = False
@@ -178,9 +197,10 @@ def test_ring_tracer_without_lights_and_without_indirect_light(mis):
     assert st["segments"] == st["paths"]                      # one segment per path: no continuation rays
 
 
-def test_ring_tracer_with_tables_too_large_for_lds(mis):
+def test_ring_tracer_with_tables_too_large_for_lds(mis, bvh_tracer):
     """More materials and more (sphere) lights than the LDS copies hold: the ring tracer reads both
-    tables from global memory; the material split alone must not change a bit."""
+    tables from global memory (the wavefront tracer's shading kernel always does); the material
+    split alone must not change a bit."""
     base, _, _, _, _ = render_both(mis)
     ref = copy.deepcopy(mis)
     n_m = len(ref.mats)
