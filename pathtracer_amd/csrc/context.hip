@@ -954,17 +954,20 @@ static void launch_wavefront(const TracePlan<R> &plan, const DScene<R> &S, const
     st.n_waves = grid_blocks * (BLOCK / 64);
     const unsigned per_path = blocks_for(B.n_paths);
     HIP_CHECK(hipMemsetAsync(st.wave_stats, 0, static_cast<size_t>(st.n_waves) * WAVE_STATS * sizeof(unsigned long long), s));
-    hipLaunchKernelGGL((k_wf_camera<R>), dim3(per_path), dim3(BLOCK), 0, s, cam, B, im.wfq[0]);
+    hipLaunchKernelGGL((k_wf_camera<R>), dim3(blocks_for(B.n_pix)), dim3(BLOCK), 0, s, cam, B, im.wfq[0]);
     for (int b = 0; b < B.depth; b++)
     {
         const WfQueue<R> &in = im.wfq[b & 1], &out = im.wfq[(b + 1) & 1];
         if (b == 0)
-            hipLaunchKernelGGL((k_wf_counts<R>), dim3(1), dim3(1), 0, s, in, static_cast<uint32_t>(B.n_paths), out);
+            hipLaunchKernelGGL((k_wf_counts<R>), dim3(1), dim3(1), 0, s, in, static_cast<uint32_t>(B.n_pix), out);
         else
             HIP_CHECK(hipMemsetAsync(out.count, 0, 8, s)); // count and pool of the queue this bounce fills
         hipLaunchKernelGGL(plan.traverse, dim3(static_cast<unsigned>(grid_blocks)), dim3(BLOCK), plan.dyn_lds, s, S, in, refill, st.wave_stats);
-        hipLaunchKernelGGL((k_wf_shade<R>), dim3(static_cast<unsigned>((B.n_paths + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK)), dim3(WF_SHADE_BLOCK), 0, s, S, B,
-                           in, out, im.wfs, b);
+        const dim3 shade_grid(static_cast<unsigned>((B.n_paths + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK));
+        if (b == 0)
+            hipLaunchKernelGGL((k_wf_shade<R, true>), shade_grid, dim3(WF_SHADE_BLOCK), 0, s, S, B, in, out, im.wfs, b);
+        else
+            hipLaunchKernelGGL((k_wf_shade<R, false>), shade_grid, dim3(WF_SHADE_BLOCK), 0, s, S, B, in, out, im.wfs, b);
     }
     hipLaunchKernelGGL((k_wf_resolve<R>), dim3(per_path), dim3(BLOCK), 0, s, S, B, im.wfs);
     HIP_CHECK(hipGetLastError());

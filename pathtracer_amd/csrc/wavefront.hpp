@@ -6,7 +6,8 @@
 // registers in double precision -- five waves per SIMD -- while a kernel that also shades needs
 // 168 (three).  So the segments of a batch of paths go through memory between two kernels:
 //
-//   k_wf_camera    one thread per path of the batch: the camera ray -> ray queue
+//   k_wf_camera    one thread per pixel of the batch: its camera ray -> ray queue (the samples of a
+//                  pixel share the ray -- the reference has no per-sample jitter -- and its hit)
 //   k_wf_traverse  persistent waves; a lane takes the next ray of the queue whenever its traversal
 //                  is complete (one atomic add per refill of a wave) and writes (t, triangle)
 //   k_wf_shade     one thread per ray of the queue: termination rules, shading normal, light
@@ -144,11 +145,13 @@ __device__ __forceinline__ void wf_path_pixel(const DBatch &B, uint32_t pid, int
     row = local_row_to_image_row(B, lr);
 }
 
-// camera rays of the batch -> queue A (cPathTracer::GenerateRay); thread 0 also sets the counts
+// camera rays of the batch -> queue A (cPathTracer::GenerateRay), ONE PER PIXEL: the reference's
+// camera rays carry no per-sample jitter, so all samples of a pixel share the ray and its closest
+// hit; the first shading launch reads entry (path id mod pixels of the batch) for every path
 template <class R> __global__ void __launch_bounds__(BLOCK) k_wf_camera(DCamera cam, DBatch B, WfQueue<R> A)
 {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= B.n_paths)
+    if (i >= B.n_pix)
         return;
     int col, row;
     wf_path_pixel(B, uint32_t(i), col, row);
@@ -174,14 +177,15 @@ template <class R> __global__ void k_wf_counts(WfQueue<R> A, uint32_t count_a, W
 // ONE atomic add (the counts of its 16 waves are summed in LDS first) -- an add per wave on the one
 // counter took longer than the shading itself.
 constexpr int WF_SHADE_BLOCK = 1024;
-template <class R>
+// CAM: the launch of bounce 0 -- one thread per path of the batch, the hit of its pixel's camera ray.
+template <class R, bool CAM>
 __global__ void __launch_bounds__(WF_SHADE_BLOCK) k_wf_shade(DScene<R> S, DBatch B, WfQueue<R> in, WfQueue<R> out, WfState<R> W, int bnc)
 {
     __shared__ uint32_t wave_cont[WF_SHADE_BLOCK / 64]; // continuation rays per wave, then their offsets in the workgroup's range
     __shared__ uint32_t block_base;
     __shared__ uint32_t block_stats[3]; // segments, shading iterations (waves), records of this workgroup
     const uint32_t i = blockIdx.x * WF_SHADE_BLOCK + threadIdx.x;
-    const uint32_t n = *in.count;
+    const uint32_t n = CAM ? uint32_t(B.n_paths) : *in.count;
     if (blockIdx.x * WF_SHADE_BLOCK >= n)
         return; // the whole workgroup is beyond the queue
     if (threadIdx.x < 3)
@@ -195,11 +199,12 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK) k_wf_shade(DScene<R> S, DBatch
     if (mine)
     {
         const size_t cap = size_t(in.cap);
-        pid = in.pid[i];
-        const V3<R> o = {in.o[i], in.o[cap + i], in.o[2 * cap + i]};
-        const V3<R> sd = {in.d[i], in.d[cap + i], in.d[2 * cap + i]};
-        const int hit_k = in.tri[i];
-        p = o + in.t[i] * sd;
+        const uint32_t e = CAM ? i % uint32_t(B.n_pix) : i; // the queue entry of this thread's segment
+        pid = CAM ? i : in.pid[e];
+        const V3<R> o = {in.o[e], in.o[cap + e], in.o[2 * cap + e]};
+        const V3<R> sd = {in.d[e], in.d[cap + e], in.d[2 * cap + e]};
+        const int hit_k = in.tri[e];
+        p = o + in.t[e] * sd;
         int col, row;
         wf_path_pixel(B, pid, col, row);
         const uint64_t key = rng_pixel_key(B.seed, uint32_t(row) * uint32_t(B.image_width) + uint32_t(col));

@@ -348,8 +348,16 @@ def test_ring_tracer_equals_lane_tracer(root, conf, kw):
             assert ("k_wf_" in c.last_kernel()) == bool(rings and extra.get("bvh_wavefront") and not square), c.last_kernel()
             if mode in out:
                 assert np.array_equal(img, out[mode][0]), (rings, extra, mode)
-                for k in ("segments", "records", "shadow_rays", "bvh_nodes", "bvh_tris", "paths"):
+                wf = "k_wf_" in c.last_kernel()
+                for k in ("segments", "records", "shadow_rays", "paths") + (() if wf else ("bvh_nodes", "bvh_tris")):
                     assert st[k] == out[mode][1][k], (k, rings, extra, mode)
+                if wf:
+                    # the samples of a pixel share their camera ray (no per-sample jitter in the reference): the
+                    # wavefront tracer traverses it once per pixel and batch, the others once per sample
+                    # (batches that hold one sample per pixel share nothing)
+                    small = "default_batch_paths" in extra
+                    assert 0 < st["bvh_nodes"] <= out[mode][1]["bvh_nodes"] and 0 < st["bvh_tris"] <= out[mode][1]["bvh_tris"]
+                    assert small or st["bvh_nodes"] < out[mode][1]["bvh_nodes"]
             else:
                 out[mode] = (img, st)
 
