@@ -162,7 +162,15 @@ void ptx_context_destroy(ptx_context *);
  * array; 0 = as many as fit at full occupancy), "bvh_rings" (1/0: BVH scenes with at most 12 lights that need
  * visibility tests are traced with per-wave hit and ray rings -- more paths in flight than lanes,
  * shading on full waves -- or with one path per lane), "ring_batch" (1..64: lanes of a wave of that
- * tracer that hand over hits / take rays together; default 40).  Results do not depend on any of
+ * tracer that hand over hits / take rays together; default 40), "bvh_wavefront" (1/0, default 1: BVH
+ * scenes whose lights need no visibility test under the reference's estimator are traced by
+ * separate traversal, shading and resolve kernels with the segments in two device-side ray queues,
+ * or by the ring tracer; its state grows with the batch: about 400 bytes per path at depth 5 in
+ * double precision), "wf_refill" (1..64: idle lanes at which a wave of that traversal kernel takes
+ * new rays; default 24), "lds_nodes" (BVH scenes: at most this many of the tree's first -- busiest
+ * -- node records in LDS behind the stack levels; -1 = what fits next to 16 stack levels, 0 = none),
+ * "raycast_wavefront" (1/0, a timing aid: ptx_raycast of unit-length directions through the
+ * wavefront tracer's traversal kernel).  Results do not depend on any of
  * them.  Set before
  * ptx_build_accel. */
 int ptx_context_set_option(ptx_context *, const char *name, int64_t value);

@@ -103,6 +103,23 @@ def main():
                              "paths_per_launch": bench["config"]["paths_per_step"] // bench["step_stats"]["passes"],
                              "kernel": k.replace("ptx::", ""),
                              "source": "profiles/%s_pmc.json (rocprofv3 --pmc on bench.py, %s)" % (tag, k)}
+        # the wavefront tracer is several kernels per batch (camera rays, traversal and shading per
+        # bounce, resolve): their counters are summed and quoted per batch, under the name of the
+        # traversal kernel (what the library reports as the tracer that ran)
+        suffix = "<double" if mode == "f64" else "<float"
+        group = {k: e for k, e in pmc.items() if "k_wf_" in k and (kname in k or suffix in k) and "SQ_INSTS_VALU" in e}
+        trav = [k for k in group if "k_wf_traverse" in k]
+        if trav and mode not in cal:
+            batches = max(1, min(e["launches"] for k, e in group.items() if "k_wf_resolve" in k) if any("k_wf_resolve" in k for k in group) else 1)
+            tot = lambda name: sum(e.get(name, 0.0) for e in group.values())
+            cal[mode] = {"valu_insts_per_wave_iteration": round(tot("SQ_INSTS_VALU") / batches / iters_per_launch, 1),
+                         "active_lanes_per_valu_inst": round(tot("SQ_THREAD_CYCLES_VALU") / tot("SQ_ACTIVE_INST_VALU") / 64.0, 4)
+                         if tot("SQ_ACTIVE_INST_VALU") else None,
+                         "hbm_bytes_per_launch": round((2.0 * tot("FETCH_SIZE") + tot("WRITE_SIZE")) * 1024 / batches),
+                         "paths_per_launch": bench["config"]["paths_per_step"] // bench["step_stats"]["passes"],
+                         "kernel": trav[0].replace("ptx::", ""),
+                         "kernels_summed": sorted(group),
+                         "source": "profiles/%s_pmc.json (rocprofv3 --pmc on bench.py, the %d k_wf_* kernels of a batch summed)" % (tag, len(group))}
     json.dump(pmc, open(os.path.join(out_dir, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
     cal_name = "calibration.json" if scene == "cbox" else "calibration_%s.json" % scene
     json.dump(cal, open(os.path.join(out_dir, cal_name), "w"), indent=1, sort_keys=True)
