@@ -88,6 +88,7 @@ struct StateNeeds
     int spill_levels = 0;  // traversal stack levels kept in global memory, per lane
     int ring_batch = 40;   // ring tracer: lanes per hand-over
     bool wavefront = false; // wavefront tracer: two ray queues, records and end states by path id instead of record slots
+    int wf_tests = 0;       // ... with visibility tests (the physically based estimator): test slots per segment = lights
 };
 
 // State region of ptx_render_static: device memory the library owns from load to unload, one
@@ -119,6 +120,7 @@ template <class R> struct Context::Impl
     DeviceBuffer state_mem; // one slab carved into the arrays of a render call (layout_state)
     DState<R> st;
     WfQueue<R> wfq[2]; // wavefront tracer: the two ray queues ...
+    WfQueue<R> wft;    // ... the queue of visibility tests (physically based estimator) ...
     WfState<R> wfs;    // ... and the per-path records and end states
     bool ready = false;
 
@@ -293,6 +295,17 @@ template <class R> struct Context::Impl
             wfs.result = st.result;
             wfs.N = n.paths;
             wfs.rows = std::max(n.waves, 1);
+            wfs.thr = wfs.pdf = wfs.term = nullptr;
+            if (n.wf_tests > 0)
+            {
+                const int64_t tcap = n.paths * n.wf_tests;
+                char *at = take(wf_queue_bytes<R>(tcap));
+                if (base)
+                    wft = wf_queue_at<R>(at, tcap);
+                wfs.term = reinterpret_cast<R *>(take(static_cast<size_t>(tcap) * 3 * sizeof(R)));
+                wfs.thr = reinterpret_cast<R *>(take(N * 3 * sizeof(R)));
+                wfs.pdf = reinterpret_cast<R *>(take(N * sizeof(R)));
+            }
         }
         st.wave_stats = reinterpret_cast<unsigned long long *>(take(static_cast<size_t>(n.waves) * WAVE_STATS * sizeof(unsigned long long)));
         st.stats = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * 8));
@@ -667,6 +680,13 @@ static BvhLdsPlan plan_bvh_lds(const void *kernel, int want_per_cu, int stack_ne
     return r;
 }
 
+template <class R> static auto wf_anyhit_kernel()
+{
+    if constexpr (sizeof(R) == 8)
+        return k_wf_anyhit_f64<0>;
+    else
+        return k_wf_anyhit_f32<0>;
+}
 template <class R> static auto wf_traverse_kernel()
 {
     if constexpr (sizeof(R) == 8)
@@ -814,7 +834,9 @@ template <class R> struct TracePlan
     bool rings = false;   // the ring tracer (needs DState::rings)
     bool ring_tests = false; // ... compiled with visibility tests (a longer ray ring)
     bool wavefront = false;  // the wavefront tracer: `traverse` instead of `kernel`, shading in kernels of its own
+    bool wf_fast = false;    // ... running the physically based estimator (visibility tests through `anyhit`)
     void (*traverse)(DScene<R>, WfQueue<R>, int, unsigned long long *) = nullptr;
+    void (*anyhit)(DScene<R>, WfQueue<R>, int, unsigned long long *) = nullptr;
 };
 
 template <class R, bool BRUTE>
@@ -903,11 +925,15 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
     }
     // BVH scenes whose lights need no visibility test (the reference's estimator without square
     // lights): traversal and shading in separate kernels, segments through two ray queues
-    if (!BRUTE && !fast && S.n_square == 0 && wavefront && rings)
+    // -- and the physically based estimator with up to 12 lights, whose visibility tests are a third
+    // queue answered by an any-hit launch per bounce
+    if (!BRUTE && wavefront && rings && (fast ? S.n_lights <= RING_MAX_TESTS : S.n_square == 0))
     {
         p.wavefront = true, p.rings = false, p.ring_tests = false;
+        p.wf_fast = fast;
         p.traverse = wf_traverse_kernel<R>();
-        p.name = sizeof(R) == 8 ? "k_wf_traverse_f64<0>" : "k_wf_traverse_f32<0>";
+        p.anyhit = wf_anyhit_kernel<R>();
+        p.name = std::string(sizeof(R) == 8 ? "k_wf_traverse_f64<0>" : "k_wf_traverse_f32<0>") + (fast ? " + k_wf_shade_fast" : "");
     }
     // BVH kernels: occupancy and the split of the dynamic LDS between stack levels and node records
     int per_cu = blocks_per_cu;
@@ -920,6 +946,8 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
         p.stack_levels = lp.levels;
         p.lds_nodes = lp.nodes;
         p.dyn_lds = lp.dyn_bytes;
+        if (p.wf_fast) // same registers, same LDS split
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(p.anyhit), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(p.dyn_lds)));
     }
     else if (per_cu <= 0)
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, p.kernel, BLOCK, 0));
@@ -964,12 +992,34 @@ static void launch_wavefront(const TracePlan<R> &plan, const DScene<R> &S, const
             HIP_CHECK(hipMemsetAsync(out.count, 0, 8, s)); // count and pool of the queue this bounce fills
         hipLaunchKernelGGL(plan.traverse, dim3(static_cast<unsigned>(grid_blocks)), dim3(BLOCK), plan.dyn_lds, s, S, in, refill, st.wave_stats);
         const dim3 shade_grid(static_cast<unsigned>((B.n_paths + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK));
-        if (b == 0)
+        if (plan.wf_fast)
+        {
+            // shading sends the visibility tests of the bounce to the test queue, an any-hit launch answers
+            // them, the gather fills in the light-sampling half of the bounce's records
+            const WfQueue<R> &tq = im.wft;
+            HIP_CHECK(hipMemsetAsync(tq.count, 0, 8, s));
+            if (b == 0)
+                hipLaunchKernelGGL((k_wf_shade_fast<R, true>), shade_grid, dim3(WF_SHADE_BLOCK), 0, s, S, B, in, out, tq, im.wfs, b);
+            else
+                hipLaunchKernelGGL((k_wf_shade_fast<R, false>), shade_grid, dim3(WF_SHADE_BLOCK), 0, s, S, B, in, out, tq, im.wfs, b);
+            if (S.n_lights > 0)
+            {
+                hipLaunchKernelGGL(plan.anyhit, dim3(static_cast<unsigned>(grid_blocks)), dim3(BLOCK), plan.dyn_lds, s, S, tq, refill, st.wave_stats);
+                if (b == 0)
+                    hipLaunchKernelGGL((k_wf_gather<R, true>), dim3(per_path), dim3(BLOCK), 0, s, B, in, tq, im.wfs, b, S.n_lights);
+                else
+                    hipLaunchKernelGGL((k_wf_gather<R, false>), dim3(per_path), dim3(BLOCK), 0, s, B, in, tq, im.wfs, b, S.n_lights);
+            }
+        }
+        else if (b == 0)
             hipLaunchKernelGGL((k_wf_shade<R, true>), shade_grid, dim3(WF_SHADE_BLOCK), 0, s, S, B, in, out, im.wfs, b);
         else
             hipLaunchKernelGGL((k_wf_shade<R, false>), shade_grid, dim3(WF_SHADE_BLOCK), 0, s, S, B, in, out, im.wfs, b);
     }
-    hipLaunchKernelGGL((k_wf_resolve<R>), dim3(per_path), dim3(BLOCK), 0, s, S, B, im.wfs);
+    if (plan.wf_fast)
+        hipLaunchKernelGGL((k_wf_resolve<R, true>), dim3(per_path), dim3(BLOCK), 0, s, S, B, im.wfs);
+    else
+        hipLaunchKernelGGL((k_wf_resolve<R, false>), dim3(per_path), dim3(BLOCK), 0, s, S, B, im.wfs);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1101,6 +1151,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
         need.waves = grid_blocks * (BLOCK / 64);
         need.slots = plan.rings ? RING_SLOTS : LANE_SLOTS;
         need.wavefront = plan.wavefront;
+        need.wf_tests = plan.wf_fast ? std::max(S.n_lights, 1) : 0;
         need.ring_bytes = plan.rings ? ring_bytes<R>(fast, plan.ring_tests) : 0;
         need.spill_levels = brute_ ? 0 : std::max(geo_->stack_need - plan.stack_levels, 0);
         need.ring_batch = ring_batch;

@@ -37,7 +37,9 @@ template <class R> struct WfQueue
 constexpr int WF_CHUNK = 256; // queue entries a wave of the traversal kernel takes per atomic add
 
 // Persistent traversal.  `refill`: a wave fetches new rays when that many of its lanes are idle.
-template <class R> __device__ __forceinline__ void wf_traverse_body(const DScene<R> &S, const WfQueue<R> &Q, int refill, unsigned long long *wave_stats)
+// ANY: the queue holds visibility tests -- segment from o along d of length t (an input here);
+// tri comes back 1 when something blocks it, else -1 (the any-hit traversal of cAccelStruct::VisTest).
+template <class R, int ANY> __device__ __forceinline__ void wf_traverse_body(const DScene<R> &S, const WfQueue<R> &Q, int refill, unsigned long long *wave_stats)
 {
     int *stk = dyn_stack + threadIdx.x;
     stage_hot_nodes(S);
@@ -74,15 +76,26 @@ template <class R> __device__ __forceinline__ void wf_traverse_body(const DScene
             {
                 o = {Q.o[i], Q.o[cap + i], Q.o[2 * cap + i]};
                 d = {Q.d[i], Q.d[cap + i], Q.d[2 * cap + i]};
-                trav_init(T, o, d);
                 idx = i, busy = true;
+                if constexpr (ANY)
+                {
+                    const R len = Q.t[i];
+                    trav_init(T, o, d, len);
+                    busy = len >= R(0); // a slot without a test
+                }
+                else
+                    trav_init(T, o, d);
             }
             next = end - next < n_idle ? end : next + n_idle;
             if (next >= n)
                 drained = true; // every ray of the queue has a lane
         }
         if (__ballot(busy) == 0ull)
-            break; // nothing left to take (drained, or the queue was empty) and every lane idle
+        {
+            if (drained)
+                break; // nothing left to take and every lane idle
+            continue;  // the slots just taken held no test: take the next ones (ends: the range only moves forward)
+        }
         // ---- traversal steps until enough lanes are idle again ----------------------------------
         for (;;)
         {
@@ -95,13 +108,15 @@ template <class R> __device__ __forceinline__ void wf_traverse_body(const DScene
             if (n_tri * 2 > (n_trav - n_tri) * 3)
             {
                 if (at_tri)
-                    more = bvh_step<R, 0, 2>(S, o, d, T, stk, n_visit);
+                    more = bvh_step<R, ANY, 2>(S, o, d, T, stk, n_visit);
             }
             else if (busy && !at_tri)
-                more = bvh_step<R, 0, 1>(S, o, d, T, stk, n_visit);
+                more = bvh_step<R, ANY, 1>(S, o, d, T, stk, n_visit);
             if (!more)
             {
-                Q.t[idx] = T.best_t, Q.tri[idx] = T.target;
+                if constexpr (!ANY)
+                    Q.t[idx] = T.best_t;
+                Q.tri[idx] = T.target;
                 busy = false;
             }
         }
@@ -116,13 +131,25 @@ template <class R> __device__ __forceinline__ void wf_traverse_body(const DScene
     }
 }
 
-template <int UNUSED = 0> __global__ void __launch_bounds__(BLOCK, 5) k_wf_traverse_f64(DScene<double> S, WfQueue<double> Q, int refill, unsigned long long *wave_stats)
+// workgroups per CU the f64 traversal kernel is compiled for (80 registers and 12 bytes of spills at 6: room +3 % over 5 with 96 registers; 7 spills more and loses 13 %)
+#ifndef PTX_WF_F64_BLOCKS
+#define PTX_WF_F64_BLOCKS 6
+#endif
+template <int UNUSED = 0> __global__ void __launch_bounds__(BLOCK, PTX_WF_F64_BLOCKS) k_wf_traverse_f64(DScene<double> S, WfQueue<double> Q, int refill, unsigned long long *wave_stats)
 {
-    wf_traverse_body<double>(S, Q, refill, wave_stats);
+    wf_traverse_body<double, 0>(S, Q, refill, wave_stats);
+}
+template <int UNUSED = 0> __global__ void __launch_bounds__(BLOCK, PTX_WF_F64_BLOCKS) k_wf_anyhit_f64(DScene<double> S, WfQueue<double> Q, int refill, unsigned long long *wave_stats)
+{
+    wf_traverse_body<double, 1>(S, Q, refill, wave_stats);
 }
 template <int UNUSED = 0> __global__ void __launch_bounds__(BLOCK, 8) k_wf_traverse_f32(DScene<float> S, WfQueue<float> Q, int refill, unsigned long long *wave_stats)
 {
-    wf_traverse_body<float>(S, Q, refill, wave_stats);
+    wf_traverse_body<float, 0>(S, Q, refill, wave_stats);
+}
+template <int UNUSED = 0> __global__ void __launch_bounds__(BLOCK, 8) k_wf_anyhit_f32(DScene<float> S, WfQueue<float> Q, int refill, unsigned long long *wave_stats)
+{
+    wf_traverse_body<float, 1>(S, Q, refill, wave_stats);
 }
 
 // per-batch state of the wavefront tracer besides the two queues
@@ -134,6 +161,13 @@ template <class R> struct WfState
     unsigned long long *wave_stats; // [rows][WAVE_STATS], added to
     int64_t N;
     int rows;
+    // physically based estimator: what a path carries from bounce to bounce, by path id -- throughput
+    // and the density its current direction was sampled with (-1: a delta lobe, -2: only delta lobes
+    // since the camera) -- and the light-sampling terms of a bounce whose visibility tests are out:
+    // the test of segment i of the queue against light l is entry i * n_lights + l of the test queue
+    // (length < 0: no test), its term beside it
+    R *thr, *pdf;                   // [3][N], [N]
+    R *term;                        // [3][test queue capacity]
 };
 
 // pixel of a path of the batch and the key of its random numbers
@@ -322,9 +356,272 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK) k_wf_shade(DScene<R> S, DBatch
     }
 }
 
+// The physically based estimator (device_math.hpp, "fast"; the FAST branches of trace_body and
+// trace_body_rings) on the wavefront tracer.  One segment per thread, in ONE pass: what the segment
+// collected besides light sampling, the termination rules, the light samples with their terms --
+// every one of them needs its visibility test, which goes to the test queue `tests` (slot segment x
+// lights + light: from the light point to the shaded point, as the reference's VisTest runs) with
+// the term beside it -- the
+// next direction, Russian roulette, the continuation ray.  The record's light-sampling half is
+// filled in by k_wf_gather once the any-hit launch has answered the tests.
+template <class R, bool CAM>
+__global__ void __launch_bounds__(WF_SHADE_BLOCK)
+    k_wf_shade_fast(DScene<R> S, DBatch B, WfQueue<R> in, WfQueue<R> out, WfQueue<R> tests, WfState<R> W, int bnc)
+{
+    __shared__ uint32_t wave_cont[WF_SHADE_BLOCK / 64];
+    __shared__ uint32_t block_base;
+    __shared__ uint32_t block_stats[4]; // segments, shading iterations (waves), records, tests of this workgroup
+    const uint32_t i = blockIdx.x * WF_SHADE_BLOCK + threadIdx.x;
+    const uint32_t n = CAM ? uint32_t(B.n_paths) : *in.count;
+    if (blockIdx.x * WF_SHADE_BLOCK >= n)
+        return; // the whole workgroup is beyond the queue
+    if (threadIdx.x < 4)
+        block_stats[threadIdx.x] = 0u;
+    const bool mine = i < n;
+    const int depth = B.depth;
+    const size_t N = size_t(W.N);
+    bool cont = false;
+    V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
+    uint32_t pid = 0, n_rec = 0, n_test = 0;
+    const size_t tcap = size_t(tests.cap), t0 = size_t(i) * size_t(S.n_lights); // this segment's test slots
+    if (i == 0u)
+        *tests.count = n * uint32_t(S.n_lights);
+    if (mine)
+    {
+        for (int l = 0; l < S.n_lights; l++)
+            tests.t[t0 + l] = R(-1); // no test until the light loop says otherwise
+        const size_t cap = size_t(in.cap);
+        const uint32_t e = CAM ? i % uint32_t(B.n_pix) : i; // the queue entry of this thread's segment
+        pid = CAM ? i : in.pid[e];
+        const V3<R> org = {in.o[e], in.o[cap + e], in.o[2 * cap + e]};
+        const V3<R> sd = {in.d[e], in.d[cap + e], in.d[2 * cap + e]};
+        const int hit_k = in.tri[e];
+        p = org + in.t[e] * sd;
+        int col, row;
+        wf_path_pixel(B, pid, col, row);
+        const uint64_t key = rng_pixel_key(B.seed, uint32_t(row) * uint32_t(B.image_width) + uint32_t(col));
+        const uint32_t sample = uint32_t(B.sample0) + pid / uint32_t(B.n_pix);
+        bool finished = false;
+        uint32_t fin_state = 0;
+        int mat_id = -1;
+        if (hit_k >= 0)
+            mat_id = S.tri_mat[hit_k];
+        const R *m = S.mats + (size_t)(mat_id < 0 ? 0 : mat_id) * MAT_STRIDE;
+        // what the path carries: throughput, the density of its current direction
+        V3<R> thr = {R(1), R(1), R(1)};
+        R pdf_prev = R(-2);
+        V3<R> other = {R(0), R(0), R(0)};
+        if (bnc > 0)
+        {
+            thr = {W.thr[pid], W.thr[N + pid], W.thr[2 * N + pid]};
+            pdf_prev = W.pdf[pid];
+        }
+        // conf lights the ray crossed before its hit: emitters that do not occlude
+        if (pdf_prev > R(-2))
+        {
+            const R t_geom = hit_k >= 0 ? norm(p - org) : Consts<R>::big;
+            for (int l = 0; l < S.n_lights; l++)
+            {
+                const R *L = S.lights + (size_t)l * LIGHT_STRIDE;
+                R tl;
+                const R pl = fast_light_pdf(L, org, sd, tl);
+                if (pl > R(0) && tl < t_geom)
+                {
+                    const R w = pdf_prev < R(0) ? R(1) : pdf_prev / (pdf_prev + pl);
+                    other = other + V3<R>{thr.x * L[1] * w, thr.y * L[2] * w, thr.z * L[3] * w};
+                }
+            }
+        }
+        R *rec = W.rec + size_t(bnc) * N + pid;
+        const size_t comp = size_t(depth) * N;
+        if (mat_id < 0 || m[13] != R(0))
+        {
+            if (mat_id >= 0 && pdf_prev == R(-2))
+                other = other + V3<R>{thr.x * m[0], thr.y * m[1], thr.z * m[2]}; // an emitter the camera sees
+            rec[0] = R(0), rec[comp] = R(0), rec[2 * comp] = R(0);
+            rec[3 * comp] = other.x, rec[4 * comp] = other.y, rec[5 * comp] = other.z;
+            n_rec = 1;
+            finished = true, fin_state = uint32_t(bnc + 1) << 16;
+        }
+        else
+        {
+            const V3<R> wo = -sd;
+            const R *__restrict__ fn = S.tri_nrm + (size_t)hit_k * 4;
+            const R fn0 = fn[0], fn1 = fn[1], fn2 = fn[2], fn3 = fn[3];
+            V3<R> nrm = {fn0, fn1, fn2};
+            if (fn3 == R(0))
+            {
+                const int face = S.tri_face[hit_k];
+                const Float9 fv = load9(S.verts + (size_t)face * 9), fq = load9(S.normals + (size_t)face * 9);
+                V3<R> a = {R(fv.v[0]), R(fv.v[1]), R(fv.v[2])}, b = {R(fv.v[3]), R(fv.v[4]), R(fv.v[5])}, c = {R(fv.v[6]), R(fv.v[7]), R(fv.v[8])};
+                V3<R> w = barycentric(p, a, b, c);
+                V3<R> acc = w.x * V3<R>{R(fq.v[0]), R(fq.v[1]), R(fq.v[2])};
+                acc = acc + w.y * V3<R>{R(fq.v[3]), R(fq.v[4]), R(fq.v[5])};
+                acc = acc + w.z * V3<R>{R(fq.v[6]), R(fq.v[7]), R(fq.v[8])};
+                nrm = fast_normalized(acc);
+            }
+            const int D0 = 4 * S.n_lights;
+            bool go_on = S.enable_indirect != 0;
+            R pdf_next = pdf_prev;
+            if (m[12] != R(0))
+            {
+                // glass: a delta lobe, no light sampling
+                if (go_on)
+                {
+                    wi = fast_glass_sample(m, nrm, wo, rng_draw<R>(key, sample, bnc, D0));
+                    pdf_next = pdf_prev == R(-2) ? R(-2) : R(-1);
+                }
+            }
+            else
+            {
+                if (dot(nrm, wo) < R(0))
+                    nrm = -nrm;
+                for (int l = 0; l < S.n_lights; l++)
+                {
+                    const R *L = S.lights + (size_t)l * LIGHT_STRIDE;
+                    const R x1 = rng_draw<R>(key, sample, bnc, 4 * l + 0);
+                    const R x2 = rng_draw<R>(key, sample, bnc, 4 * l + 1);
+                    V3<R> wl, q;
+                    const R pl = fast_light_sample(L, p, x1, x2, wl, q);
+                    if (!(pl > R(0)))
+                        continue;
+                    R pb;
+                    const V3<R> f = fast_brdf(m, nrm, wo, wl, pb);
+                    const R cn = dot(nrm, wl);
+                    if (!(cn > R(0)))
+                        continue;
+                    // cos / pl times the balance weight pl / (pl + pb); at the last bounce the light sample counts whole
+                    const R w = (go_on && bnc + 1 < depth) ? cn / (pl + pb) : cn / pl;
+                    // the test: the segment from the light point to the shaded point, as visible() runs it
+                    const size_t r = t0 + l;
+                    const R dist = norm(q - p);
+                    const V3<R> dir = normalized(p - q);
+                    tests.o[r] = q.x, tests.o[tcap + r] = q.y, tests.o[2 * tcap + r] = q.z;
+                    tests.d[r] = dir.x, tests.d[tcap + r] = dir.y, tests.d[2 * tcap + r] = dir.z;
+                    tests.t[r] = dist;
+                    W.term[r] = thr.x * L[1] * f.x * w, W.term[tcap + r] = thr.y * L[2] * f.y * w, W.term[2 * tcap + r] = thr.z * L[3] * f.z * w;
+                    n_test++;
+                }
+                if (go_on)
+                {
+                    const R x0 = rng_draw<R>(key, sample, bnc, D0), x1 = rng_draw<R>(key, sample, bnc, D0 + 1);
+                    const R x2 = rng_draw<R>(key, sample, bnc, D0 + 2);
+                    go_on = fast_brdf_sample(m, nrm, wo, x0, x1, x2, wi);
+                    if (go_on)
+                    {
+                        R pb;
+                        const V3<R> f = fast_brdf(m, nrm, wo, wi, pb);
+                        go_on = pb > R(0);
+                        if (go_on)
+                        {
+                            const R c = dot(nrm, wi) / pb;
+                            thr = {thr.x * (f.x * c), thr.y * (f.y * c), thr.z * (f.z * c)};
+                            pdf_next = pb;
+                        }
+                    }
+                }
+            }
+            // the light-sampling half of the record is k_wf_gather's
+            rec[0] = R(0), rec[comp] = R(0), rec[2 * comp] = R(0);
+            rec[3 * comp] = other.x, rec[4 * comp] = other.y, rec[5 * comp] = other.z;
+            n_rec = 1;
+            if (go_on && bnc >= 3)
+            {
+                // Russian roulette
+                const R q = fmin(max3(thr.x, thr.y, thr.z), R(0.95));
+                go_on = rng_draw<R>(key, sample, bnc, D0 + 3) < q;
+                if (go_on)
+                    thr = {thr.x / q, thr.y / q, thr.z / q};
+            }
+            if (go_on && bnc + 1 < depth)
+            {
+                cont = true;
+                W.thr[pid] = thr.x, W.thr[N + pid] = thr.y, W.thr[2 * N + pid] = thr.z;
+                W.pdf[pid] = pdf_next;
+            }
+            else
+                finished = true, fin_state = uint32_t(bnc + 1) << 16;
+        }
+        if (finished)
+            W.fin[pid] = fin_state;
+    }
+    // ---- continuation rays -> the other queue: one range per workgroup ----------------------------------
+    const unsigned long long cm = __ballot(cont);
+    const unsigned long long mm = __ballot(mine);
+    const unsigned long long rm = __ballot(n_rec != 0u);
+    const int lane = lane_id(), wave = int(threadIdx.x >> 6);
+    uint32_t wave_tests = n_test;
+    for (int off = 32; off > 0; off >>= 1)
+        wave_tests += uint32_t(__shfl_xor(int(wave_tests), off, 64));
+    __syncthreads(); // block_stats is zero
+    if (lane == 0)
+    {
+        wave_cont[wave] = uint32_t(__popcll(cm));
+        if (mm != 0ull)
+        {
+            atomicAdd(&block_stats[0], uint32_t(__popcll(mm)));
+            atomicAdd(&block_stats[1], 1u);
+            atomicAdd(&block_stats[2], uint32_t(__popcll(rm)));
+            atomicAdd(&block_stats[3], wave_tests);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t total = 0;
+        for (int w = 0; w < WF_SHADE_BLOCK / 64; w++)
+        {
+            const uint32_t c = wave_cont[w];
+            wave_cont[w] = total;
+            total += c;
+        }
+        block_base = total ? atomicAdd(out.count, total) : 0u;
+        unsigned long long *row = W.wave_stats + size_t(blockIdx.x % uint32_t(W.rows)) * WAVE_STATS;
+        atomicAdd(row + 0, (unsigned long long)block_stats[0]);
+        atomicAdd(row + 1, (unsigned long long)block_stats[3]);
+        atomicAdd(row + 2, (unsigned long long)block_stats[1]);
+        atomicAdd(row + 3, (unsigned long long)block_stats[2]);
+    }
+    __syncthreads();
+    if (cont)
+    {
+        const size_t r = size_t(block_base) + wave_cont[wave] + rank_in(cm), cap = size_t(out.cap);
+        out.o[r] = p.x, out.o[cap + r] = p.y, out.o[2 * cap + r] = p.z;
+        out.d[r] = wi.x, out.d[cap + r] = wi.y, out.d[2 * cap + r] = wi.z;
+        out.pid[r] = pid;
+    }
+}
+
+// After the any-hit launch: the light-sampling half of every record of the bounce = the terms of the
+// segment's unblocked tests, added in light order (the order of the sequential light loop).
+template <class R, bool CAM> __global__ void __launch_bounds__(BLOCK) k_wf_gather(DBatch B, WfQueue<R> in, WfQueue<R> tests, WfState<R> W, int bnc, int n_lights)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t n = CAM ? uint32_t(B.n_paths) : *in.count;
+    if (i >= n)
+        return;
+    const size_t tb = size_t(i) * size_t(n_lights), cap = size_t(tests.cap), N = size_t(W.N);
+    V3<R> direct = {R(0), R(0), R(0)};
+    bool any = false;
+    for (int l = 0; l < n_lights; l++)
+        if (tests.t[tb + l] >= R(0))
+        {
+            any = true;
+            if (tests.tri[tb + l] != 1)
+                direct = direct + V3<R>{W.term[tb + l], W.term[cap + tb + l], W.term[2 * cap + tb + l]};
+        }
+    if (!any)
+        return; // the record's light-sampling half stays zero
+    const uint32_t pid = CAM ? i : in.pid[i];
+    R *rec = W.rec + size_t(bnc) * N + pid;
+    const size_t comp = size_t(B.depth) * N;
+    rec[0] = direct.x, rec[comp] = direct.y, rec[2 * comp] = direct.z;
+}
+
 // One path per thread: its bounce records folded back to front with the per-bounce max-clamp
-// (cPathTracer.cpp:679-689), the per-sample result stored for k_accumulate.
-template <class R> __global__ void __launch_bounds__(BLOCK) k_wf_resolve(DScene<R> S, DBatch B, WfState<R> W)
+// (cPathTracer.cpp:679-689), the per-sample result stored for k_accumulate.  FAST: every term
+// already carries its throughput, the path's radiance is their plain sum.
+template <class R, bool FAST> __global__ void __launch_bounds__(BLOCK) k_wf_resolve(DScene<R> S, DBatch B, WfState<R> W)
 {
 #pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
     const int64_t pid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -343,6 +640,11 @@ template <class R> __global__ void __launch_bounds__(BLOCK) k_wf_resolve(DScene<
     for (int i = len - 1; i >= 0; i--)
     {
         const R *q = W.rec + size_t(i) * N + size_t(pid);
+        if constexpr (FAST)
+        {
+            fr += q[0] + q[3 * comp], fg += q[comp] + q[4 * comp], fb += q[2 * comp] + q[5 * comp];
+            continue;
+        }
         fr = q[0] + q[3 * comp] * fr;
         fg = q[comp] + q[4 * comp] * fg;
         fb = q[2 * comp] + q[5 * comp] * fb;

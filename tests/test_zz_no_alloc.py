@@ -63,14 +63,17 @@ def test_static_state_render_with_visibility_tests_in_the_rings(root):
     BVH scene with square lights under the reference's estimator: the static region holds a smaller
     grid of them, with the same results as the allocating entry point."""
     s, _ = load(root, "config/mis.conf", width=96, height=64, spp=3)
-    c = make_ctx(s)
-    for mode in ("f64", "f32"):
-        a, b, sa, sb = both(c, (64, 96, 3), mode=mode, estimator="fast")
-        assert c.last_kernel().startswith("k_trace_rings_fast")
-        assert sa["state_bytes"] <= 256 << 20
-        if mode == "f64":
-            assert np.abs(a - b).max() <= 1e-9 * max(1.0, float(b.max())) and a.max() > 0
-        assert all(sa[k] == sb[k] for k in ("paths", "segments", "shadow_rays", "records"))
+    for wavefront in (0, 1):                                                   # ring tracer; wavefront tracer (test queue, any-hit launches)
+        c = pt.Context(0)
+        c.set_option("bvh_wavefront", wavefront)
+        c.build_accel(s)
+        for mode in ("f64", "f32"):
+            a, b, sa, sb = both(c, (64, 96, 3), mode=mode, estimator="fast")
+            assert c.last_kernel().startswith("k_wf_traverse" if wavefront else "k_trace_rings_fast")
+            assert sa["state_bytes"] <= 256 << 20
+            if mode == "f64":
+                assert np.abs(a - b).max() <= 1e-9 * max(1.0, float(b.max())) and a.max() > 0
+            assert all(sa[k] == sb[k] for k in ("paths", "segments", "shadow_rays", "records"))
     s2, _ = load(root, "config/cbox.conf", width=64, height=48, spp=4)
     c2 = pt.Context(0, brute_force_limit=0)                                    # the Cornell box on the BVH: its square light is tested through the rings
     c2.build_accel(s2)
