@@ -164,7 +164,7 @@ template <class R> struct WfState
     // physically based estimator: what a path carries from bounce to bounce, by path id -- throughput
     // and the density its current direction was sampled with (-1: a delta lobe, -2: only delta lobes
     // since the camera) -- and the light-sampling terms of a bounce whose visibility tests are out:
-    // the test of segment i of the queue against light l is entry i * n_lights + l of the test queue
+    // the test of segment i of the queue's n against light l is entry l * n + i of the test queue
     // (length < 0: no test), its term beside it
     R *thr, *pdf;                   // [3][N], [N]
     R *term;                        // [3][test queue capacity]
@@ -359,9 +359,9 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK) k_wf_shade(DScene<R> S, DBatch
 // The physically based estimator (device_math.hpp, "fast"; the FAST branches of trace_body and
 // trace_body_rings) on the wavefront tracer.  One segment per thread, in ONE pass: what the segment
 // collected besides light sampling, the termination rules, the light samples with their terms --
-// every one of them needs its visibility test, which goes to the test queue `tests` (slot segment x
-// lights + light: from the light point to the shaded point, as the reference's VisTest runs) with
-// the term beside it -- the
+// every one of them needs its visibility test, which goes to the test queue `tests` (slot light x
+// segments + segment, so that neighbouring threads write neighbouring slots: from the light point to
+// the shaded point, as the reference's VisTest runs) with the term beside it -- the
 // next direction, Russian roulette, the continuation ray.  The record's light-sampling half is
 // filled in by k_wf_gather once the any-hit launch has answered the tests.
 template <class R, bool CAM>
@@ -383,13 +383,13 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK)
     bool cont = false;
     V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
     uint32_t pid = 0, n_rec = 0, n_test = 0;
-    const size_t tcap = size_t(tests.cap), t0 = size_t(i) * size_t(S.n_lights); // this segment's test slots
+    const size_t tcap = size_t(tests.cap), t0 = size_t(i), tstep = size_t(n); // this segment's test slots: t0 + light * tstep
     if (i == 0u)
         *tests.count = n * uint32_t(S.n_lights);
     if (mine)
     {
         for (int l = 0; l < S.n_lights; l++)
-            tests.t[t0 + l] = R(-1); // no test until the light loop says otherwise
+            tests.t[t0 + l * tstep] = R(-1); // no test until the light loop says otherwise
         const size_t cap = size_t(in.cap);
         const uint32_t e = CAM ? i % uint32_t(B.n_pix) : i; // the queue entry of this thread's segment
         pid = CAM ? i : in.pid[e];
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK)
                     // cos / pl times the balance weight pl / (pl + pb); at the last bounce the light sample counts whole
                     const R w = (go_on && bnc + 1 < depth) ? cn / (pl + pb) : cn / pl;
                     // the test: the segment from the light point to the shaded point, as visible() runs it
-                    const size_t r = t0 + l;
+                    const size_t r = t0 + l * tstep;
                     const R dist = norm(q - p);
                     const V3<R> dir = normalized(p - q);
                     tests.o[r] = q.x, tests.o[tcap + r] = q.y, tests.o[2 * tcap + r] = q.z;
@@ -600,16 +600,19 @@ template <class R, bool CAM> __global__ void __launch_bounds__(BLOCK) k_wf_gathe
     const uint32_t n = CAM ? uint32_t(B.n_paths) : *in.count;
     if (i >= n)
         return;
-    const size_t tb = size_t(i) * size_t(n_lights), cap = size_t(tests.cap), N = size_t(W.N);
+    const size_t cap = size_t(tests.cap), N = size_t(W.N);
     V3<R> direct = {R(0), R(0), R(0)};
     bool any = false;
     for (int l = 0; l < n_lights; l++)
-        if (tests.t[tb + l] >= R(0))
+    {
+        const size_t r = size_t(i) + size_t(l) * size_t(n); // light by light, consecutive segments side by side
+        if (tests.t[r] >= R(0))
         {
             any = true;
-            if (tests.tri[tb + l] != 1)
-                direct = direct + V3<R>{W.term[tb + l], W.term[cap + tb + l], W.term[2 * cap + tb + l]};
+            if (tests.tri[r] != 1)
+                direct = direct + V3<R>{W.term[r], W.term[cap + r], W.term[2 * cap + r]};
         }
+    }
     if (!any)
         return; // the record's light-sampling half stays zero
     const uint32_t pid = CAM ? i : in.pid[i];
