@@ -36,7 +36,7 @@ VALU_ISSUE_PEAK = N_SIMD * CLOCK_GHZ / 2.0   # G wave64 instructions/s: a SIMD-3
 VALU_ISSUE_PEAK_F64 = N_SIMD * CLOCK_GHZ / 4.0  # f64 arithmetic runs at half that rate (78.6 TFLOP/s FMA)
 
 
-def algorithmic_bytes(mode, st, n_pix_touched):
+def algorithmic_bytes(mode, st, n_pix_touched, wavefront=False):
     """HBM bytes each kernel must move for the work of one step (scene tables excluded: they are a
     few KB read through the scalar cache / LDS).  R = size of the scalar type.
       k_trace ...... writes one 6-scalar (direct, coefficient) record per shaded segment and 3 result scalars
@@ -45,6 +45,13 @@ def algorithmic_bytes(mode, st, n_pix_touched):
       k_accumulate . reads 3 scalars per path, reads + writes the f64 rgb sum of every pixel it touches"""
     R = 8 if mode == "f64" else 4
     rec, paths = st["records"], st["paths"]
+    if wavefront:
+        # the wavefront tracer of BVH scenes moves its segments through memory on purpose: per segment
+        # the ray written by the shading kernel (6R + 4) and read by the traversal kernel (6R), the hit
+        # written (R + 4) and the whole entry read by the shading kernel (7R + 8); per record 6R written
+        # and read back by the resolve kernel; per path the end-state word (written, read) and 3R of result
+        return {"trace": st["segments"] * (20 * R + 16) + rec * 12 * R + paths * (3 * R + 8),
+                "accumulate": paths * 3 * R + n_pix_touched * 48}
     return {"trace": rec * 6 * R + paths * 3 * R,
             "accumulate": paths * 3 * R + n_pix_touched * 48}
 
@@ -135,6 +142,9 @@ def main():
     ap.add_argument("--conf", default="config/cbox.conf")
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-estimator", action="store_true",
+                    help="skip the one step of the physically based estimator that is run for the record (profiling sessions: "
+                         "the wavefront tracer's traversal kernel serves both estimators, and counters are summed per kernel)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--scheme", default="samples", choices=["samples", "bands"],
                     help="multi-GPU sharding: 'samples' = every rank renders --spp samples of every pixel (weak "
@@ -240,7 +250,8 @@ def main():
         torch.cuda.synchronize()
         ms = {"trace": ps["ms_trace"], "accumulate": ps["ms_accumulate"]}
         passes = int(ps["passes"])
-        ab = algorithmic_bytes(args.mode, ps, int(ps["paths"]) // args.spp * passes)  # pixels of this rank x launches
+        wavefront = ctx.last_kernel().startswith("k_wf_")
+        ab = algorithmic_bytes(args.mode, ps, int(ps["paths"]) // args.spp * passes, wavefront)  # pixels of this rank x launches
         dom = max(ms, key=ms.get)
         kernels = {}
         for k in ms:
@@ -267,9 +278,14 @@ def main():
                              if ctx.accel_info()["brute_force"] else
                              "achieved prices the data streams of the algorithm (f32 SoA ray / hit / shadow / stack "
                              "streams plus 32 B per BVH node and 48 B per triangle visited, %.0f B per path on this "
-                             "scene); rays and hits stay in registers, LDS and wave-private rings, the BVH records and "
-                             "the path records do go through memory (traffic, PMC); the kernel is bound by memory "
-                             "latency and traversal divergence, see valu")
+                             "scene); " + ("the wavefront tracer moves rays, hits and records through device-side queues "
+                                           "between its traversal, shading and resolve kernels (design_*: what those streams "
+                                           "amount to in this precision; traffic, PMC: all kernels of a batch, BVH records "
+                                           "included); the traversal kernel is bound by the latency of dependent record "
+                                           "fetches at 6 (f32: 8) waves per SIMD and by divergence, see valu" if wavefront else
+                                           "rays and hits stay in registers, LDS and wave-private rings, the BVH records and "
+                                           "the path records do go through memory (traffic, PMC); the kernel is bound by memory "
+                                           "latency and traversal divergence, see valu"))
                             % (stream_bytes * passes / max(ps["paths"], 1))}
         # counter calibrations are per scene (and only quoted at the launch size they were collected at)
         cal = pmc_calibration(args.mode, scene_name)
@@ -308,7 +324,7 @@ def main():
         # the physically based estimator on the same frame, one step, for the record (another
         # estimator: its paths are shorter and every light costs a visibility test; not the metric)
         fast = None
-        if world == 1:
+        if world == 1 and not args.no_fast_estimator:
             render_fn(out, spp=1, sample_offset=0, spp_total=1, mode=args.mode, seed=13, estimator="fast")   # its kernel and state, untimed
             torch.cuda.synchronize()
             t1 = time.perf_counter()
