@@ -1157,7 +1157,9 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
         need.ring_bytes = plan.rings ? ring_bytes<R>(fast, plan.ring_tests) : 0;
         need.spill_levels = brute_ ? 0 : std::max(geo_->stack_need - plan.stack_levels, 0);
         need.ring_batch = ring_batch;
-        if (im.layout_state(nullptr, need, &spill) <= budget)
+        // (the wavefront tracer's test queue is indexed with 32 bits: batch x lights must stay below 2^31)
+        const bool queue_ok = need.wf_tests == 0 || cap * need.wf_tests < (int64_t(1) << 31);
+        if (queue_ok && im.layout_state(nullptr, need, &spill) <= budget)
             break;
         // too large: first smaller batches (they cost a few per cent at most), then a smaller grid
         if (batch > std::max<int64_t>(n_cols, int64_t(1) << 18))
