@@ -164,10 +164,10 @@ void ptx_context_destroy(ptx_context *);
  * shading on full waves -- or with one path per lane), "ring_batch" (1..64: lanes of a wave of that
  * tracer that hand over hits / take rays together; default 40), "bvh_wavefront" (1/0, default 1: BVH
  * scenes whose lights need no visibility test under the reference's estimator, and BVH scenes with
- * up to 12 lights under the physically based one, are traced by separate traversal, shading and
+ * up to 12 lights otherwise (square lights, the physically based estimator), are traced by separate traversal, shading and
  * resolve kernels with the segments in device-side ray queues, or by the ring tracer; its state
  * grows with the batch: about 400 bytes per path at depth 5 in double precision, plus 84 per light
- * and path under the physically based estimator), "wf_refill" (1..64: idle lanes at which a wave of that traversal kernel takes
+ * and path where lights need visibility tests), "wf_refill" (1..64: idle lanes at which a wave of that traversal kernel takes
  * new rays; default 24), "lds_nodes" (BVH scenes: at most this many of the tree's first -- busiest
  * -- node records in LDS behind the stack levels; -1 = what fits next to 16 stack levels, 0 = none),
  * "raycast_wavefront" (1/0, a timing aid: ptx_raycast of unit-length directions through the

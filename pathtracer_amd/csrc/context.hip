@@ -835,6 +835,7 @@ template <class R> struct TracePlan
     bool ring_tests = false; // ... compiled with visibility tests (a longer ray ring)
     bool wavefront = false;  // the wavefront tracer: `traverse` instead of `kernel`, shading in kernels of its own
     bool wf_fast = false;    // ... running the physically based estimator (visibility tests through `anyhit`)
+    bool wf_sq = false;      // ... running the reference's estimator on a scene with square lights (their tests likewise)
     void (*traverse)(DScene<R>, WfQueue<R>, int, unsigned long long *) = nullptr;
     void (*anyhit)(DScene<R>, WfQueue<R>, int, unsigned long long *) = nullptr;
 };
@@ -927,13 +928,15 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
     // lights): traversal and shading in separate kernels, segments through two ray queues
     // -- and the physically based estimator with up to 12 lights, whose visibility tests are a third
     // queue answered by an any-hit launch per bounce
-    if (!BRUTE && wavefront && rings && (fast ? S.n_lights <= RING_MAX_TESTS : S.n_square == 0))
+    // -- and scenes with square lights and at most 12 lights in all, the same way
+    if (!BRUTE && wavefront && rings && (S.n_lights <= RING_MAX_TESTS || (!fast && S.n_square == 0)))
     {
         p.wavefront = true, p.rings = false, p.ring_tests = false;
         p.wf_fast = fast;
+        p.wf_sq = !fast && S.n_square > 0;
         p.traverse = wf_traverse_kernel<R>();
         p.anyhit = wf_anyhit_kernel<R>();
-        p.name = std::string(sizeof(R) == 8 ? "k_wf_traverse_f64<0>" : "k_wf_traverse_f32<0>") + (fast ? " + k_wf_shade_fast" : "");
+        p.name = std::string(sizeof(R) == 8 ? "k_wf_traverse_f64<0>" : "k_wf_traverse_f32<0>") + (fast ? " + k_wf_shade_fast" : p.wf_sq ? " + k_wf_anyhit" : "");
     }
     // BVH kernels: occupancy and the split of the dynamic LDS between stack levels and node records
     int per_cu = blocks_per_cu;
@@ -946,7 +949,7 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
         p.stack_levels = lp.levels;
         p.lds_nodes = lp.nodes;
         p.dyn_lds = lp.dyn_bytes;
-        if (p.wf_fast) // same registers, same LDS split
+        if (p.wf_fast || p.wf_sq) // same registers, same LDS split
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(p.anyhit), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(p.dyn_lds)));
     }
     else if (per_cu <= 0)
@@ -1011,10 +1014,25 @@ static void launch_wavefront(const TracePlan<R> &plan, const DScene<R> &S, const
                     hipLaunchKernelGGL((k_wf_gather<R, false>), dim3(per_path), dim3(BLOCK), 0, s, B, in, tq, im.wfs, b, S.n_lights);
             }
         }
+        else if (plan.wf_sq)
+        {
+            // the reference's estimator with square lights: the same three steps
+            const WfQueue<R> &tq = im.wft;
+            HIP_CHECK(hipMemsetAsync(tq.count, 0, 8, s));
+            if (b == 0)
+                hipLaunchKernelGGL((k_wf_shade<R, true, true>), shade_grid, dim3(WF_SHADE_BLOCK), 0, s, S, B, in, out, tq, im.wfs, b);
+            else
+                hipLaunchKernelGGL((k_wf_shade<R, false, true>), shade_grid, dim3(WF_SHADE_BLOCK), 0, s, S, B, in, out, tq, im.wfs, b);
+            hipLaunchKernelGGL(plan.anyhit, dim3(static_cast<unsigned>(grid_blocks)), dim3(BLOCK), plan.dyn_lds, s, S, tq, refill, st.wave_stats);
+            if (b == 0)
+                hipLaunchKernelGGL((k_wf_gather<R, true>), dim3(per_path), dim3(BLOCK), 0, s, B, in, tq, im.wfs, b, S.n_lights);
+            else
+                hipLaunchKernelGGL((k_wf_gather<R, false>), dim3(per_path), dim3(BLOCK), 0, s, B, in, tq, im.wfs, b, S.n_lights);
+        }
         else if (b == 0)
-            hipLaunchKernelGGL((k_wf_shade<R, true>), shade_grid, dim3(WF_SHADE_BLOCK), 0, s, S, B, in, out, im.wfs, b);
+            hipLaunchKernelGGL((k_wf_shade<R, true, false>), shade_grid, dim3(WF_SHADE_BLOCK), 0, s, S, B, in, out, im.wfq[0], im.wfs, b);
         else
-            hipLaunchKernelGGL((k_wf_shade<R, false>), shade_grid, dim3(WF_SHADE_BLOCK), 0, s, S, B, in, out, im.wfs, b);
+            hipLaunchKernelGGL((k_wf_shade<R, false, false>), shade_grid, dim3(WF_SHADE_BLOCK), 0, s, S, B, in, out, im.wfq[0], im.wfs, b);
     }
     if (plan.wf_fast)
         hipLaunchKernelGGL((k_wf_resolve<R, true>), dim3(per_path), dim3(BLOCK), 0, s, S, B, im.wfs);
@@ -1127,7 +1145,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     // resolve pass), so the state does not grow with the batch except for 3 scalars per path.
     // (the wavefront tracer runs one traversal launch per bounce of the whole batch and gains from
     // larger ones -- room: +3 % at 2^26 paths, +8 % at 2^27 -- at 400 to 900 bytes of state per path: twice the default)
-    int64_t batch = o.batch_paths > 0 ? o.batch_paths : default_batch_paths * ((plan.wavefront && !plan.wf_fast) ? 2 : 1); // (its test queue makes the other estimator's state 2 to 5 times larger: no doubling there)
+    int64_t batch = o.batch_paths > 0 ? o.batch_paths : default_batch_paths * ((plan.wavefront && !plan.wf_fast && !plan.wf_sq) ? 2 : 1); // (its test queue makes the other estimator's state 2 to 5 times larger: no doubling there)
     batch = std::max<int64_t>(batch, n_cols);
     int grid_blocks = static_cast<int>(std::min<int64_t>(static_cast<int64_t>(plan.blocks_per_cu) * n_cus_, MAX_TRACE_WAVES / (BLOCK / 64)));
     size_t budget = STATIC_STATE_BYTES;
@@ -1153,7 +1171,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
         need.waves = grid_blocks * (BLOCK / 64);
         need.slots = plan.rings ? RING_SLOTS : LANE_SLOTS;
         need.wavefront = plan.wavefront;
-        need.wf_tests = plan.wf_fast ? std::max(S.n_lights, 1) : 0;
+        need.wf_tests = (plan.wf_fast || plan.wf_sq) ? std::max(S.n_lights, 1) : 0;
         need.ring_bytes = plan.rings ? ring_bytes<R>(fast, plan.ring_tests) : 0;
         need.spill_levels = brute_ ? 0 : std::max(geo_->stack_need - plan.stack_levels, 0);
         need.ring_batch = ring_batch;

@@ -212,26 +212,38 @@ template <class R> __global__ void k_wf_counts(WfQueue<R> A, uint32_t count_a, W
 // counter took longer than the shading itself.
 constexpr int WF_SHADE_BLOCK = 1024;
 // CAM: the launch of bounce 0 -- one thread per path of the batch, the hit of its pixel's camera ray.
-template <class R, bool CAM>
-__global__ void __launch_bounds__(WF_SHADE_BLOCK) k_wf_shade(DScene<R> S, DBatch B, WfQueue<R> in, WfQueue<R> out, WfState<R> W, int bnc)
+// SQ: the scene has square lights (at most 12 lights in all), whose samples need the reference's
+// visibility test: every light with a term gets its slot light x segments + segment of the test
+// queue -- a square light's the segment from the light point to the shaded point, a sphere light's
+// the mark "counts without a test" (length -2) -- with the term beside it, the record's direct half
+// is left to k_wf_gather, which adds the terms in light order once the any-hit launch has run.
+template <class R, bool CAM, bool SQ>
+__global__ void __launch_bounds__(WF_SHADE_BLOCK)
+    k_wf_shade(DScene<R> S, DBatch B, WfQueue<R> in, WfQueue<R> out, WfQueue<R> tests, WfState<R> W, int bnc)
 {
     __shared__ uint32_t wave_cont[WF_SHADE_BLOCK / 64]; // continuation rays per wave, then their offsets in the workgroup's range
     __shared__ uint32_t block_base;
-    __shared__ uint32_t block_stats[3]; // segments, shading iterations (waves), records of this workgroup
+    __shared__ uint32_t block_stats[4]; // segments, shading iterations (waves), records, tests of this workgroup
     const uint32_t i = blockIdx.x * WF_SHADE_BLOCK + threadIdx.x;
     const uint32_t n = CAM ? uint32_t(B.n_paths) : *in.count;
     if (blockIdx.x * WF_SHADE_BLOCK >= n)
         return; // the whole workgroup is beyond the queue
-    if (threadIdx.x < 3)
+    if (threadIdx.x < 4)
         block_stats[threadIdx.x] = 0u;
     const bool mine = i < n;
     const int depth = B.depth;
     const size_t N = size_t(W.N);
     bool cont = false;
     V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
-    uint32_t pid = 0, n_rec = 0;
+    uint32_t pid = 0, n_rec = 0, n_test = 0;
+    const size_t tcap = size_t(tests.cap), t0 = size_t(i), tstep = size_t(n); // this segment's test slots: t0 + light * tstep
+    if (SQ && i == 0u)
+        *tests.count = n * uint32_t(S.n_lights);
     if (mine)
     {
+        if constexpr (SQ)
+            for (int l = 0; l < S.n_lights; l++)
+                tests.t[t0 + l * tstep] = R(-1); // no term until the light loop says otherwise
         const size_t cap = size_t(in.cap);
         const uint32_t e = CAM ? i % uint32_t(B.n_pix) : i; // the queue entry of this thread's segment
         pid = CAM ? i : in.pid[e];
@@ -282,7 +294,12 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK) k_wf_shade(DScene<R> S, DBatch
                 V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
                 const R x1 = rng_draw<R>(key, sample, bnc, 4 * l + 0);
                 const R x2 = rng_draw<R>(key, sample, bnc, 4 * l + 1);
-                const R pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bnc, 4 * l + 2), ro, rd);
+                const bool square = SQ && L[0] == R(0);
+                R pdf;
+                if (square)
+                    pdf = square_light_sample(L, p, x1, x2, ro, rd);
+                else
+                    pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bnc, 4 * l + 2), ro, rd);
                 if (pdf < R(1e-10))
                     continue;
                 const R cn = dot(nrm, -rd);
@@ -290,7 +307,26 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK) k_wf_shade(DScene<R> S, DBatch
                     continue;
                 const V3<R> f = bxdf_eval(m, rd, wo, nrm);
                 const R w = cn / pdf;
-                direct = direct + V3<R>{(L[1] * w) * f.x, (L[2] * w) * f.y, (L[3] * w) * f.z};
+                const V3<R> term = {(L[1] * w) * f.x, (L[2] * w) * f.y, (L[3] * w) * f.z};
+                if constexpr (SQ)
+                {
+                    const size_t r = t0 + l * tstep;
+                    W.term[r] = term.x, W.term[tcap + r] = term.y, W.term[2 * tcap + r] = term.z;
+                    if (square)
+                    {
+                        // the segment from the light point to the shaded point, as visible() runs it
+                        const R dist = norm(ro - p);
+                        const V3<R> dir = normalized(p - ro);
+                        tests.o[r] = ro.x, tests.o[tcap + r] = ro.y, tests.o[2 * tcap + r] = ro.z;
+                        tests.d[r] = dir.x, tests.d[tcap + r] = dir.y, tests.d[2 * tcap + r] = dir.z;
+                        tests.t[r] = dist;
+                        n_test++;
+                    }
+                    else
+                        tests.t[r] = R(-2); // a sphere light: its term counts without a test
+                }
+                else
+                    direct = direct + term;
             }
             // ---- next direction and indirect coefficient ---------------------------------------------
             V3<R> coef = {R(0), R(0), R(0)};
@@ -318,16 +354,22 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK) k_wf_shade(DScene<R> S, DBatch
     const unsigned long long mm = __ballot(mine);
     const unsigned long long rm = __ballot(n_rec != 0u);
     const int lane = lane_id(), wave = int(threadIdx.x >> 6);
+    uint32_t wave_tests = n_test;
+    if constexpr (SQ)
+        for (int off = 32; off > 0; off >>= 1)
+            wave_tests += uint32_t(__shfl_xor(int(wave_tests), off, 64));
     __syncthreads(); // block_stats is zero
     if (lane == 0)
     {
         wave_cont[wave] = uint32_t(__popcll(cm));
         if (mm != 0ull)
         {
-            // statistics: segments, one 64-lane shading iteration, records
+            // statistics: segments, one 64-lane shading iteration, records, visibility tests
             atomicAdd(&block_stats[0], uint32_t(__popcll(mm)));
             atomicAdd(&block_stats[1], 1u);
             atomicAdd(&block_stats[2], uint32_t(__popcll(rm)));
+            if (SQ)
+                atomicAdd(&block_stats[3], wave_tests);
         }
     }
     __syncthreads();
@@ -343,6 +385,8 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK) k_wf_shade(DScene<R> S, DBatch
         block_base = total ? atomicAdd(out.count, total) : 0u;
         unsigned long long *row = W.wave_stats + size_t(blockIdx.x % uint32_t(W.rows)) * WAVE_STATS;
         atomicAdd(row + 0, (unsigned long long)block_stats[0]);
+        if (SQ)
+            atomicAdd(row + 1, (unsigned long long)block_stats[3]);
         atomicAdd(row + 2, (unsigned long long)block_stats[1]);
         atomicAdd(row + 3, (unsigned long long)block_stats[2]);
     }
@@ -606,10 +650,11 @@ template <class R, bool CAM> __global__ void __launch_bounds__(BLOCK) k_wf_gathe
     for (int l = 0; l < n_lights; l++)
     {
         const size_t r = size_t(i) + size_t(l) * size_t(n); // light by light, consecutive segments side by side
-        if (tests.t[r] >= R(0))
+        const R len = tests.t[r];
+        if (len >= R(0) || len == R(-2)) // a test, or a term that counts without one
         {
             any = true;
-            if (tests.tri[r] != 1)
+            if (len < R(0) || tests.tri[r] != 1)
                 direct = direct + V3<R>{W.term[r], W.term[cap + r], W.term[2 * cap + r]};
         }
     }

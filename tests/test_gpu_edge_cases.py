@@ -227,8 +227,9 @@ def test_ring_tracer_with_tables_too_large_for_lds(mis, bvh_tracer):
 
 
 @pytest.mark.parametrize("position", [0, 3])
-def test_ring_tracer_with_one_square_light_among_sphere_lights(mis, position):
-    """The square light's visibility tests go round the rings; the light sum keeps the light order
+def test_ring_tracer_with_one_square_light_among_sphere_lights(mis, position, bvh_tracer):
+    """The square light's visibility tests go round the rings (wavefront tracer: through the test queue,
+    the sphere lights' terms in slots that count without a test); the light sum keeps the light order
     whether the square light comes first or in the middle."""
     ref = copy.deepcopy(mis)
     lo, hi = ref.verts.reshape(-1, 3).min(0), ref.verts.reshape(-1, 3).max(0)
@@ -240,11 +241,12 @@ def test_ring_tracer_with_one_square_light_among_sphere_lights(mis, position):
     ref.lights = np.insert(ref.lights, position, L, axis=0)
     img, st, oimg, ost, c_ = render_both(ref)
     assert not c_.accel_info()["brute_force"]
+    assert_tracer(c_, bvh_tracer)
     assert st["shadow_rays"] > 0
     assert_f64_parity(img, oimg, st, ost)
 
 
-def test_ring_tracer_with_several_square_lights(mis):
+def test_ring_tracer_with_several_square_lights(mis, bvh_tracer):
     """Every square light with a valid sample costs the hit one more trip round the rings; results
     and test counts are those of the lane tracer and of the oracle."""
     ref = copy.deepcopy(mis)
@@ -266,6 +268,7 @@ def test_ring_tracer_with_several_square_lights(mis):
     ref.lights = np.array(lights)
     img, st, oimg, ost, c_ = render_both(ref)
     assert not c_.accel_info()["brute_force"]
+    assert_tracer(c_, bvh_tracer)                                  # nine lights, four of them square: within the wavefront tracer's twelve
     assert st["shadow_rays"] > st["segments"]                      # more than one test per segment on average
     assert_f64_parity(img, oimg, st, ost)
     lane = pt.Context(0)

@@ -325,12 +325,11 @@ def test_bvh_stack_spill_is_bit_invariant(root, conf, kw):
 def test_ring_tracer_equals_lane_tracer(root, conf, kw):
     """BVH scenes with at most one square light (the Cornell box forced onto the BVH: its visibility
     tests travel through the rings too): the tracer that queues hits and rays per wave (more paths
-    in flight than lanes), the one that keeps every path on its lane and -- scenes without square
-    lights -- the wavefront tracer render the same bits, run the same visibility tests and visit
+    in flight than lanes), the one that keeps every path on its lane and the wavefront tracer (the
+    Cornell box's visibility tests through its test queue) render the same bits, run the same visibility tests and visit
     the same BVH records, whatever the grid, the batches and the LDS share of the stacks and nodes."""
     s, ref = load(root, conf, **kw)
     out = {}
-    square = conf.endswith("cbox.conf")   # its light needs visibility tests: no wavefront tracer
     for rings, extra in ((0, {}), (1, dict(bvh_wavefront=0)), (1, dict(bvh_wavefront=0, trace_blocks_per_cu=1, lds_stack_levels=4)),
                          (1, dict(bvh_wavefront=0, chunk_paths=4096, lds_nodes=0)),
                          # the wavefront tracer (traversal and shading in separate kernels): default options, one workgroup
@@ -345,7 +344,7 @@ def test_ring_tracer_equals_lane_tracer(root, conf, kw):
         assert not c.accel_info()["brute_force"]
         for mode in ("f64", "f32"):
             img, st = c.render(mode=mode)
-            assert ("k_wf_" in c.last_kernel()) == bool(rings and extra.get("bvh_wavefront") and not square), c.last_kernel()
+            assert ("k_wf_" in c.last_kernel()) == bool(rings and extra.get("bvh_wavefront")), c.last_kernel()
             if mode in out:
                 assert np.array_equal(img, out[mode][0]), (rings, extra, mode)
                 wf = "k_wf_" in c.last_kernel()

@@ -75,11 +75,13 @@ def test_static_state_render_with_visibility_tests_in_the_rings(root):
                 assert np.abs(a - b).max() <= 1e-9 * max(1.0, float(b.max())) and a.max() > 0
             assert all(sa[k] == sb[k] for k in ("paths", "segments", "shadow_rays", "records"))
     s2, _ = load(root, "config/cbox.conf", width=64, height=48, spp=4)
-    c2 = pt.Context(0, brute_force_limit=0)                                    # the Cornell box on the BVH: its square light is tested through the rings
-    c2.build_accel(s2)
-    a, b, sa, sb = both(c2, (48, 64, 3), mode="f64")
-    assert c2.last_kernel() == "k_trace_rings_f64<true, true>"
-    assert np.array_equal(a, b) and sa["shadow_rays"] == sb["shadow_rays"] > 0
+    for wavefront in (0, 1):
+        c2 = pt.Context(0, brute_force_limit=0)                                # the Cornell box on the BVH: its square light is tested through the rings / the test queue
+        c2.set_option("bvh_wavefront", wavefront)
+        c2.build_accel(s2)
+        a, b, sa, sb = both(c2, (48, 64, 3), mode="f64")
+        assert c2.last_kernel() == ("k_wf_traverse_f64<0> + k_wf_anyhit" if wavefront else "k_trace_rings_f64<true, true>")
+        assert np.array_equal(a, b) and sa["shadow_rays"] == sb["shadow_rays"] > 0
 
 
 def test_static_state_render_rejects_what_does_not_fit(root):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times a BVH scene WITH a square light (room.obj, its lamps replaced by one square light under the
-ceiling) with the ring tracer and with the lane tracer: time_square_bvh.py [width] [spp] [mode]."""
+ceiling) with the wavefront tracer, the ring tracer and the lane tracer: time_square_bvh.py [width] [spp] [mode]."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -24,14 +24,15 @@ ref.lights = np.array([L])
 scene = pt.Scene.from_arrays(ref.verts.astype(np.float32), ref.normals.astype(np.float32), ref.mat_ids, ref.mats, ref.lights,
                              ref.view, ref.cam_pos, ref.fov_deg, ref.near, W, W, ref.depth, spp, ref.enable_indirect, ref.enable_bary_normal)
 imgs = []
-for rings in (1, 0):
+for rings, wavefront in ((1, 1), (1, 0), (0, 0)):   # wavefront tracer, ring tracer, lane tracer
     ctx = pt.Context(0)
     ctx.set_option("bvh_rings", rings)
+    ctx.set_option("bvh_wavefront", wavefront)
     ctx.build_accel(scene)
     out = torch.zeros((W, W, 3), dtype=torch.float64, device="cuda")
     ctx.render_device(out.data_ptr(), mode=mode, spp=1)
     st = ctx.render_device(out.data_ptr(), mode=mode, spp=spp)
     imgs.append(out.cpu().numpy())
-    print("rings=%d %s: %.1f Mpaths/s (%.1f ms), %.2f segments/path, %.2f shadow rays/path" % (
-        rings, mode, st["paths"] / st["ms_total"] / 1e3, st["ms_total"], st["segments"] / st["paths"], st["shadow_rays"] / st["paths"]), flush=True)
-print("identical:", bool(np.array_equal(imgs[0], imgs[1])))
+    print("%s %s: %.1f Mpaths/s (%.1f ms), %.2f segments/path, %.2f shadow rays/path" % (
+        ctx.last_kernel(), mode, st["paths"] / st["ms_total"] / 1e3, st["ms_total"], st["segments"] / st["paths"], st["shadow_rays"] / st["paths"]), flush=True)
+print("identical:", bool(np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[1], imgs[2])))
