@@ -94,6 +94,7 @@ def main():
     a = ap.parse_args()
     template = scene_io.load_conf(os.path.join(ROOT, "config/cbox.conf"), root_dir=ROOT, width=a.size, height=a.size, spp=2)
     failures = 0
+    kernels = {}   # tracer kernel -> renders it ran
     for seed in range(a.first, a.first + a.seeds):
         ref = scene(seed, template)
         s = pt.Scene.from_arrays(ref.verts.astype(np.float32), ref.normals.astype(np.float32), ref.mat_ids, ref.mats, ref.lights, ref.view,
@@ -107,6 +108,7 @@ def main():
                 c = pt.Context(0, brute_force_limit=limit)
                 c.build_accel(s)
                 img, st = c.render(mode="f64", seed=13, estimator=est)
+                kernels[c.last_kernel()] = kernels.get(c.last_kernel(), 0) + 1
                 try:
                     n_bad = assert_f64_parity(img, oimg, st, ost, depth=ref.depth, ctx=c, O=O, render_kw=dict(estimator=est))
                     if n_bad:
@@ -116,6 +118,8 @@ def main():
                     notes.append("%s/%s FAILED: %s" % (est, c.last_kernel(), str(e)[:300]))
         print("seed %d: %d faces, %d lights, depth %d, %d spp%s" % (seed, ref.verts.shape[0], ref.lights.shape[0], ref.depth, ref.spp,
                                                                    "".join("; " + x for x in notes)), flush=True)
+    for k in sorted(kernels):
+        print("renders through %s: %d" % (k, kernels[k]), flush=True)
     print("TOTAL failures: %d" % failures, flush=True)
     return 1 if failures else 0
 
