@@ -979,7 +979,7 @@ static void launch_trace(const TracePlan<R> &plan, const DScene<R> &S, const DCa
 // traversal kernel (the spill columns and the statistics rows were laid out for them).
 template <class R>
 static void launch_wavefront(const TracePlan<R> &plan, const DScene<R> &S, const DCamera &cam, const DBatch &B, Context::Impl<R> &im, hipStream_t s,
-                             int grid_blocks, int refill)
+                             int grid_blocks, int refill, unsigned long long *pinned_word)
 {
     DState<R> &st = im.st;
     st.n_waves = grid_blocks * (BLOCK / 64);
@@ -989,6 +989,17 @@ static void launch_wavefront(const TracePlan<R> &plan, const DScene<R> &S, const
     for (int b = 0; b < B.depth; b++)
     {
         const WfQueue<R> &in = im.wfq[b & 1], &out = im.wfq[(b + 1) & 1];
+        // Deep scenes: most paths end long before Depth.  From bounce 8 on, every eighth bounce reads
+        // the count of the queue it is about to traverse back (4 bytes into pinned memory, one wait)
+        // and stops when no ray is left; scenes of ordinary depth never get here.
+        if (b >= 8 && (b & 7) == 0)
+        {
+            *pinned_word = 1ull;
+            HIP_CHECK(hipMemcpyAsync(pinned_word, in.count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            if (static_cast<uint32_t>(*pinned_word) == 0u)
+                break;
+        }
         if (b == 0)
             hipLaunchKernelGGL((k_wf_counts<R>), dim3(1), dim3(1), 0, s, in, static_cast<uint32_t>(B.n_pix), out);
         else
@@ -1136,8 +1147,29 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     RenderTimers *tm = (o.profile && !static_state) ? &timers_ : nullptr;
     // The grid of the tracer is just large enough to fill the device: its waves are persistent.
     const bool fast = o.estimator == PTX_ESTIMATOR_FAST_;
-    const TracePlan<R> plan = brute_ ? plan_trace<R, true>(S, trace_blocks_per_cu, shadow_queue, 0, 0, false, fast)
-                                    : plan_trace<R, false>(S, trace_blocks_per_cu, shadow_queue, geo_->stack_need, lds_stack_levels, bvh_rings, fast, lds_nodes, bvh_wavefront);
+    TracePlan<R> plan = brute_ ? plan_trace<R, true>(S, trace_blocks_per_cu, shadow_queue, 0, 0, false, fast)
+                              : plan_trace<R, false>(S, trace_blocks_per_cu, shadow_queue, geo_->stack_need, lds_stack_levels, bvh_rings, fast, lds_nodes, bvh_wavefront);
+    if (plan.wavefront)
+    {
+        // The wavefront tracer keeps depth records per path of a batch: at a depth where even its
+        // smallest batch does not fit the memory there is (or the static region), the scene goes to the
+        // ring / lane tracers, whose record slots belong to the grid and shrink with it.
+        size_t room = STATIC_STATE_BYTES;
+        if (!static_state)
+        {
+            size_t free_b = 0, total_b = 0;
+            HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+            room = static_cast<size_t>(0.9 * static_cast<double>(free_b + im.state_mem.bytes));
+        }
+        StateNeeds least;
+        least.paths = std::max<int64_t>(c1 - c0, int64_t(1) << 18), least.depth = depth;
+        least.waves = plan.blocks_per_cu * n_cus_ * (BLOCK / 64), least.slots = 0, least.wavefront = true;
+        least.wf_tests = (plan.wf_fast || plan.wf_sq) ? std::max(S.n_lights, 1) : 0;
+        least.spill_levels = std::max(geo_->stack_need - plan.stack_levels, 0);
+        uint32_t *unused = nullptr;
+        if (im.layout_state(nullptr, least, &unused) > room)
+            plan = plan_trace<R, false>(S, trace_blocks_per_cu, shadow_queue, geo_->stack_need, lds_stack_levels, bvh_rings, fast, lds_nodes, false);
+    }
     last_kernel_ = plan.name;
 
     // ---- size the batch and the grid so that the state fits the memory there is --------------
@@ -1231,7 +1263,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
             if (tm)
                 tm->mark(s, RenderTimers::TRACE);
             if (plan.wavefront)
-                launch_wavefront<R>(plan, S, cam, B, im, s, grid_blocks, wf_refill);
+                launch_wavefront<R>(plan, S, cam, B, im, s, grid_blocks, wf_refill, host_stats_ + 7);
             else
                 launch_trace<R>(plan, S, cam, B, im.st, s, chunk, grid_blocks);
             launch_finish<R>(S, B, im.st, d_sum, s, tm);

@@ -279,6 +279,31 @@ def test_ring_tracer_with_several_square_lights(mis, bvh_tracer):
     assert (lst["segments"], lst["shadow_rays"], lst["records"]) == (st["segments"], st["shadow_rays"], st["records"])
 
 
+def test_wavefront_tracer_at_great_depths(mis):
+    """A depth far beyond the length of any path: the wavefront tracer stops launching once its ray
+    queue is empty (same bits and counts as the ring tracer, which has no such loop); at a depth whose
+    records do not fit the memory for even its smallest batch the scene goes to the ring tracer."""
+    ref = copy.deepcopy(mis)
+    scene = gpu_scene(ref)
+    out = {}
+    for wavefront in (0, 1):
+        c = pt.Context(0)
+        c.set_option("bvh_wavefront", wavefront)
+        c.build_accel(scene)
+        img, st = c.render(mode="f64", seed=13, depth=300)
+        assert ("k_wf_" in c.last_kernel()) == bool(wavefront)
+        out[wavefront] = (img, st)
+        if wavefront:
+            deep, std = c.render(mode="f64", seed=13, depth=65535)      # 48 B x 65535 per path: no batch of it fits
+            assert "k_trace_rings" in c.last_kernel()
+            assert std["segments"] >= st["segments"] and np.isfinite(deep).all()
+            again, st2 = c.render(mode="f64", seed=13, depth=300)       # and back
+            assert "k_wf_" in c.last_kernel() and np.array_equal(again, img) and st2["segments"] == st["segments"]
+    assert np.array_equal(out[0][0], out[1][0])
+    assert all(out[0][1][k] == out[1][1][k] for k in ("paths", "segments", "records"))
+    assert out[0][1]["segments"] < 40 * out[0][1]["paths"]              # nowhere near 300 segments per path
+
+
 def test_state_that_does_not_fit_shrinks_or_fails_cleanly(cbox):
     """The path state is sized against the memory there is: a depth whose record slots would take
     terabytes on the full grid runs on a smaller one, a request that cannot be met at all comes back
