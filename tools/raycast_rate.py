@@ -23,6 +23,10 @@ def main():
     ap.add_argument("conf")
     ap.add_argument("--rays", type=int, default=1 << 22)
     ap.add_argument("--variants", default="", help="option sets (name=value,...) separated by ';': one context and two calls each")
+    ap.add_argument("--sort", default="none", choices=["none", "origin", "origin+octant", "octant+origin"],
+                    help="order of the rays: as drawn, by the Morton code of the origin's cell (2^bits per axis), the direction "
+                         "octant within a cell, or the cell within an octant")
+    ap.add_argument("--bits", type=int, default=7)
     a = ap.parse_args()
     s = pt.Scene.load_conf(os.path.join(ROOT, a.conf), root_dir=ROOT, width=1024, height=1024, spp=1)
     c = pt.Context(0)
@@ -37,6 +41,18 @@ def main():
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     flip = np.einsum("ij,ij->i", d, cam - o) < 0
     d[flip] *= -1
+    if a.sort != "none":
+        lo, hi = o.min(0), o.max(0)
+        q = np.minimum(((o - lo) / (hi - lo + 1e-12) * (1 << a.bits)).astype(np.uint64), (1 << a.bits) - 1)
+        morton = np.zeros(len(o), dtype=np.uint64)
+        for b in range(a.bits):
+            for k in range(3):
+                morton |= ((q[:, k] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + k)
+        octant = ((d[:, 0] < 0).astype(np.uint64) | ((d[:, 1] < 0).astype(np.uint64) << np.uint64(1)) | ((d[:, 2] < 0).astype(np.uint64) << np.uint64(2)))
+        key = {"origin": morton, "origin+octant": (morton << np.uint64(3)) | octant, "octant+origin": (octant << np.uint64(3 * a.bits)) | morton}[a.sort]
+        order = np.argsort(key, kind="stable")
+        o, d = np.ascontiguousarray(o[order]), np.ascontiguousarray(d[order])
+        print("rays sorted by %s, %d bits per axis" % (a.sort, a.bits), flush=True)
     ref = None
     for rep in range(3):
         t0 = time.time()

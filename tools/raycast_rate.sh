@@ -5,9 +5,9 @@ R=$(pwd)
 O=$R/gpurun_out/raycast_rate
 rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-PTX_DEBUG=1 timeout -k 10 280 rocprofv3 --kernel-trace --output-format csv -d $O -o rr -- python3 $R/tools/raycast_rate.py $1 --variants "$2" > $O/run.log 2>&1 || { tail -5 $O/run.log; exit 1; }
+PTX_DEBUG=1 timeout -k 10 280 rocprofv3 --kernel-trace --output-format csv -d $O -o rr -- python3 $R/tools/raycast_rate.py $1 --variants "$2" $3 $4 $5 $6 > $O/run.log 2>&1 || { tail -5 $O/run.log; exit 1; }
 cd $R
-grep -E "operator|wavefront|differ" $O/run.log | sort -u
+grep -E "operator|wavefront|differ|sorted" $O/run.log | sort -u
 python3 - $O <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
