@@ -34,7 +34,16 @@ template <class R> struct WfQueue
     int64_t cap;
 };
 
-constexpr int WF_CHUNK = 256; // queue entries a wave of the traversal kernel takes per atomic add
+// a wave runs a triangle step (exact test in R) instead of a node step (four f32 slab tests) when
+// lanes at triangles x A > lanes at nodes x B
+#ifndef PTX_WF_TRI_A
+#define PTX_WF_TRI_A 2
+#define PTX_WF_TRI_B 3
+#endif
+#ifndef PTX_WF_CHUNK
+#define PTX_WF_CHUNK 256
+#endif
+constexpr int WF_CHUNK = PTX_WF_CHUNK; // queue entries a wave of the traversal kernel takes per atomic add
 
 // Persistent traversal.  `refill`: a wave fetches new rays when that many of its lanes are idle.
 // ANY: the queue holds visibility tests -- segment from o along d of length t (an input here);
@@ -105,7 +114,7 @@ template <class R, int ANY> __device__ __forceinline__ void wf_traverse_body(con
             const bool at_tri = busy && T.cur >= S.n_nodes;
             const int n_tri = __popcll(__ballot(at_tri));
             bool more = true;
-            if (n_tri * 2 > (n_trav - n_tri) * 3)
+            if (n_tri * PTX_WF_TRI_A > (n_trav - n_tri) * PTX_WF_TRI_B)
             {
                 if (at_tri)
                     more = bvh_step<R, ANY, 2>(S, o, d, T, stk, n_visit);
