@@ -228,9 +228,12 @@ def test_render_flags_and_region(root):
             assert (img[:5] == 0).all() and (img[21:] == 0).all()
 
 
-def test_draw_region_from_conf(root, tmp_path):
+@pytest.mark.parametrize("name,estimator", [("cbox", "reference"), ("mis", "reference"), ("mis", "fast")])
+def test_draw_region_from_conf(root, tmp_path, name, estimator):
+    """DrawRegion sub-window (rows 3..17, columns 5..29, inclusive): the all-triangles tracer on the
+    Cornell box, the wavefront tracer on mis under both estimators; pixels outside stay 0."""
     import json
-    conf = json.load(open(os.path.join(root, "config/cbox.conf")))
+    conf = json.load(open(os.path.join(root, "config/%s.conf" % name)))
     conf["MainWindowInfo"]["Width"] = conf["MainWindowInfo"]["Height"] = 36
     conf["PathTracer"]["DrawRegion"] = [3, 5, 17, 29]
     conf["PathTracer"]["Samples"] = 3
@@ -239,13 +242,20 @@ def test_draw_region_from_conf(root, tmp_path):
     s = pt.Scene.load_conf(str(p), root_dir=root)
     ref = scene_io.load_conf(str(p), root_dir=root, full_region=False)
     assert tuple(ref.region) == (3, 5, 17, 29)
-    c, O = make_ctx(s), oracle.Oracle(ref, seed=13)
-    img, _ = c.render(mode="f64")
+    c, O = make_ctx(s), oracle.Oracle(ref, seed=13, estimator=estimator)
+    img, st = c.render(mode="f64", estimator=estimator)
+    assert ("k_wf_" in c.last_kernel()) == (name == "mis")
+    assert st["paths"] == 15 * 25 * 3
     oimg = O.render()
-    assert_f64_parity(img, oimg, ctx=c, O=O)
+    scale = np.maximum(1.0, np.abs(oimg).max(axis=-1, keepdims=True))
+    assert_f64_parity(img / scale, oimg / scale, ctx=c, O=O, render_kw=dict(estimator=estimator))
     mask = np.zeros((36, 36), bool)
     mask[3:18, 5:30] = True
     assert (img[~mask] == 0).all()
+    # rows of the window in two pieces and a batch per few pixels add up to the same sums
+    top, _ = c.render(mode="f64", estimator=estimator, rows=(0, 10), batch_paths=50)
+    both, _ = c.render(mode="f64", estimator=estimator, rows=(10, 36), accumulate=True, out=top)
+    assert np.array_equal(both, img)
 
 
 def test_batching_sharding_and_bands_are_bit_invariant(cbox64):
