@@ -154,7 +154,7 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
     // the ray this lane is traversing
     bool busy = false, done = false; // done: traversal complete, the hit waits to be handed over
     Trav<R> T;
-    trav_init(T, V3<R>{R(0), R(0), R(0)}, V3<R>{R(1), R(1), R(1)});
+    trav_init(S, T, V3<R>{R(0), R(0), R(0)}, V3<R>{R(1), R(1), R(1)});
     V3<R> o = {R(0), R(0), R(0)}, d = {R(0), R(0), R(0)};
     uint32_t bounce = 0; // state word of the ray this lane traverses
     // a visibility test in flight: the hit it belongs to (handed back when the test is done)
@@ -741,11 +741,11 @@ __device__ __forceinline__ void trace_body_rings(const DScene<R> &S, const DCame
                         s = square_light_point(L, x1, x2);
                     const R dist = norm(s - vp);
                     o = s, d = normalized(vp - s);
-                    trav_init(T, o, d, dist);
+                    trav_init(S, T, o, d, dist);
                     T.any = 1;
                 }
                 else
-                    trav_init(T, o, d);
+                    trav_init(S, T, o, d);
                 busy = true, done = false;
             }
             const uint32_t taken = min(uint32_t(__popcll(fm)), rq_count);

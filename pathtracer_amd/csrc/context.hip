@@ -341,6 +341,7 @@ struct Context::Geometry
     float smax = 0.f;
     int n_nodes = 0, id_bits = 1; // 4-wide BVH: node records, bits of the record id in a stack entry
     int stack_need = 1;           // stack entries a traversal can need
+    float cmax = 0.f;             // largest |coordinate| of the root node's child boxes
 };
 
 // 64-byte device nodes: corner and cell size of an 8-bit grid over the union of the child boxes,
@@ -528,6 +529,16 @@ void Context::build_accel(const Scene &sc)
     geo_->n_nodes = static_cast<int>(bvh_.nodes.size());
     geo_->id_bits = id_bits_;
     geo_->stack_need = std::max(bvh_.stack_need, 1);
+    {
+        // the root's child boxes hold the whole scene (padded): bound of every |coordinate| a slab test meets
+        float cm = 0.f;
+        if (!bvh_.nodes.empty())
+            for (int k = 0; k < 3; k++)
+                for (int j = 0; j < 4; j++)
+                    if (bvh_.nodes[0].child[j] != BVH_EMPTY)
+                        cm = std::max(cm, std::max(std::fabs(bvh_.nodes[0].lo[k][j]), std::fabs(bvh_.nodes[0].hi[k][j])));
+        geo_->cmax = cm;
+    }
     geo_->smax = pr.smax;
     f64_->build_tables(sc, bvh_, brute_, s);
     f32_->build_tables(sc, bvh_, brute_, s);
@@ -548,7 +559,8 @@ template <class R> static DScene<R> make_dscene(const Scene &sc, const Context::
     S.enable_bary = sc.enable_bary_normal && sc.has_normals;
     S.n_recs = g.n_recs;
     S.pq_smax = g.smax;
-    S.pad_[0] = S.pad_[1] = S.pad_[2] = 0.f;
+    S.bvh_cmax = g.cmax;
+    S.pad_[0] = S.pad_[1] = 0.f;
     S.tri_pre = static_cast<const R *>(tri_pre);
     S.tri_pq = static_cast<const float *>(g.tri_pq.p);
     S.rec_tri = static_cast<const int32_t *>(g.rec_tri.p);

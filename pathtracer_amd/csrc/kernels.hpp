@@ -33,7 +33,8 @@ template <class R> struct DScene
 {
     int n_tris, n_mats, n_lights, n_square;
     int brute, enable_indirect, enable_bary, n_recs;
-    float pq_smax, pad_[3];    // largest |c| of the plane records
+    float pq_smax;             // largest |c| of the plane records
+    float bvh_cmax, pad_[2];   // largest |coordinate| of the BVH's root box (slab margins, trav_init)
     const R *tri_pre;          // [n_tris][12] in intersector order: p1, p1-p2, p1-p3, cofactors
     const float *tri_pq;       // [n_recs][32] f32 plane records (all-triangles intersector)
     const int32_t *rec_tri;    // [64] candidate bit -> triangle, -1: none
@@ -301,14 +302,22 @@ template <class R> struct Trav
     float onx, ony, onz, ofx, ofy, ofz; // end of the origin interval that makes the near / far plane of a slab nearer / farther
     float ivx, ivy, ivz;                // 1 / d, finite
 };
-template <class R> __device__ __forceinline__ void trav_init(Trav<R> &T, V3<R> o, V3<R> d, R limit = Consts<R>::big)
+template <class R> __device__ __forceinline__ void trav_init(const DScene<R> &S, Trav<R> &T, V3<R> o, V3<R> d, R limit = Consts<R>::big)
 {
     T.cur = 0, T.sp = 0, T.target = -1, T.best_face = 0x7fffffff;
     T.any = 0;
     T.best = limit;
     T.best_t = R(0);
     const float fx = float(o.x), fy = float(o.y), fz = float(o.z);
-    const float P = 0x1p-22f * fmaxf(fmaxf(fabsf(fx), fabsf(fy)), fabsf(fz)) + 1e-30f;
+    const float omax = fmaxf(fmaxf(fabsf(fx), fabsf(fy)), fabsf(fz));
+    // Half width of the origin interval: 2^-22 |o| for the rounding of the origin to f32, plus the
+    // bound of the roundings of a slab's plane distance t = A q + B (A = cell * slope, q <= 255,
+    // B = (corner - origin) * slope), taken once per ray instead of once per node: those roundings
+    // are below 2^-21 (255 |A| + |B|) (bvh_step), 255 |A| is at most the extent of a node's box and
+    // |B| at most |corner| + |origin|, each times |slope| -- so four times that bound is at most
+    // 2^-19 (3 Cmax + |o|) |slope| with Cmax the largest |coordinate| of the root box, and moving
+    // the origin end by 2^-19 (3 Cmax + |o|) moves the plane distance by exactly that much the safe way.
+    const float P = 0x1p-22f * omax + 0x1p-19f * (3.0f * S.bvh_cmax + omax) + 1e-30f;
     const float big = 1.0e18f; // an axis the ray does not move along: a huge finite slope keeps infinities out of the slabs
     // 1 / d from the f32 reciprocal instruction (1 ulp) of the rounded direction: 1.5 * 2^-23 in
     // all, well inside the margins by which bvh_step widens every slab
@@ -438,17 +447,12 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
         const float tmaxf = float(T.best) * (1.0f + K) + 1e-30f;
         // plane distance t = A * q + B per axis, A = cell * slope, B = (corner - origin) * slope, with
         // the origin end and the plane (low or high) that make a near plane nearer and a far plane
-        // farther; the roundings of A, B and of the sum are bounded by 2^-21 (255 |A| + |B|); four
-        // times that is taken off the near planes and added to the far ones
+        // farther; the roundings of A, B and of the sum are bounded by 2^-21 (255 |A| + |B|)
         const float Ax = __uint_as_float(n1.x) * T.ivx, Ay = __uint_as_float(n1.y) * T.ivy, Az = __uint_as_float(n1.z) * T.ivz;
-        float Bnx = (__uint_as_float(n0.x) - T.onx) * T.ivx, Bfx = (__uint_as_float(n0.x) - T.ofx) * T.ivx;
-        float Bny = (__uint_as_float(n0.y) - T.ony) * T.ivy, Bfy = (__uint_as_float(n0.y) - T.ofy) * T.ivy;
-        float Bnz = (__uint_as_float(n0.z) - T.onz) * T.ivz, Bfz = (__uint_as_float(n0.z) - T.ofz) * T.ivz;
-        constexpr float M = 0x1p-19f;
-        const float mx = M * (255.0f * fabsf(Ax) + fmaxf(fabsf(Bnx), fabsf(Bfx)));
-        const float my = M * (255.0f * fabsf(Ay) + fmaxf(fabsf(Bny), fabsf(Bfy)));
-        const float mz = M * (255.0f * fabsf(Az) + fmaxf(fabsf(Bnz), fabsf(Bfz)));
-        Bnx -= mx, Bfx += mx, Bny -= my, Bfy += my, Bnz -= mz, Bfz += mz;
+        // (the margin for the roundings of A, B and of the sum is part of the origin interval, see trav_init)
+        const float Bnx = (__uint_as_float(n0.x) - T.onx) * T.ivx, Bfx = (__uint_as_float(n0.x) - T.ofx) * T.ivx;
+        const float Bny = (__uint_as_float(n0.y) - T.ony) * T.ivy, Bfy = (__uint_as_float(n0.y) - T.ofy) * T.ivy;
+        const float Bnz = (__uint_as_float(n0.z) - T.onz) * T.ivz, Bfz = (__uint_as_float(n0.z) - T.ofz) * T.ivz;
         const bool px = T.ivx >= 0.0f, py = T.ivy >= 0.0f, pz = T.ivz >= 0.0f;
         const uint32_t qnx = px ? n2.x : n2.y, qfx = px ? n2.y : n2.x; // near / far plane coordinates of the four children
         const uint32_t qny = py ? n2.z : n2.w, qfy = py ? n2.w : n2.z;
@@ -608,7 +612,7 @@ __device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d,
     }
     Trav<R> T;
     uint32_t visits[2] = {0, 0};
-    trav_init(T, o, du); // slab distances along the unit direction: same units as T.best
+    trav_init(S, T, o, du); // slab distances along the unit direction: same units as T.best
     while (bvh_step<R, false>(S, o, d, T, stk, visits))
     {
     }
@@ -647,7 +651,7 @@ __device__ __forceinline__ bool visible(const DScene<R> &S, V3<R> p1, V3<R> p2, 
         return !blocked;
     }
     Trav<R> T;
-    trav_init(T, p1, dir, dist);
+    trav_init(S, T, p1, dir, dist);
     uint32_t none[2] = {0, 0};
     while (bvh_step<R, true>(S, p1, dir, T, stk, visits ? visits : none))
     {
@@ -914,7 +918,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
     bool alive = false;
     bool trav_done = false; // BVH: the lane's closest-hit traversal is complete (its path waits for shading)
     Trav<R> T;
-    trav_init(T, V3<R>{R(0), R(0), R(0)}, V3<R>{R(1), R(1), R(1)});
+    trav_init(S, T, V3<R>{R(0), R(0), R(0)}, V3<R>{R(1), R(1), R(1)});
     V3<R> o = {R(0), R(0), R(0)}, d = {R(0), R(0), R(0)};
     uint32_t pid = 0, sample = 0;
     int bounce = 0, prim = -1;
@@ -1167,7 +1171,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 if constexpr (FAST)
                     thr = {R(1), R(1), R(1)}, pdf_prev = R(-2);
                 if constexpr (!BRUTE)
-                    trav_init(T, o, d), trav_done = false;
+                    trav_init(S, T, o, d), trav_done = false;
             }
         }
         {
@@ -1359,7 +1363,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                     bounce++;
                     alive = true;
                     if constexpr (!BRUTE)
-                        trav_init(T, o, d), trav_done = false;
+                        trav_init(S, T, o, d), trav_done = false;
                 }
                 else
                     finished = true, fin_state = uint32_t(bounce + 1) << 16;
@@ -1451,7 +1455,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 bounce++;
                 alive = true;
                 if constexpr (!BRUTE)
-                    trav_init(T, o, d), trav_done = false;
+                    trav_init(S, T, o, d), trav_done = false;
             }
             else
                 finished = true, fin_state = uint32_t(bounce + 1) << 16;

@@ -59,7 +59,7 @@ template <class R, int ANY> __device__ __forceinline__ void wf_traverse_body(con
     uint32_t idx = 0;
     uint32_t next = 0, end = 0; // the wave's current range of queue entries (wave-uniform)
     Trav<R> T;
-    trav_init(T, V3<R>{R(0), R(0), R(0)}, V3<R>{R(1), R(1), R(1)});
+    trav_init(S, T, V3<R>{R(0), R(0), R(0)}, V3<R>{R(1), R(1), R(1)});
     V3<R> o = {R(0), R(0), R(0)}, d = {R(0), R(0), R(0)};
     uint32_t n_visit[2] = {0, 0};
     const size_t cap = size_t(Q.cap);
@@ -89,11 +89,11 @@ template <class R, int ANY> __device__ __forceinline__ void wf_traverse_body(con
                 if constexpr (ANY)
                 {
                     const R len = Q.t[i];
-                    trav_init(T, o, d, len);
+                    trav_init(S, T, o, d, len);
                     busy = len >= R(0); // a slot without a test
                 }
                 else
-                    trav_init(T, o, d);
+                    trav_init(S, T, o, d);
             }
             next = end - next < n_idle ? end : next + n_idle;
             if (next >= n)
