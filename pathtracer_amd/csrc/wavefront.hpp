@@ -216,10 +216,21 @@ template <class R> __global__ void k_wf_counts(WfQueue<R> A, uint32_t count_a, W
 // normal, light sampling over all lights in order, next direction: cPathTracer.cpp:598-673,
 // cBxDF::Sample_Li cBxDF.cpp:16-52 of the reference; scenes without square lights, so no
 // visibility test), its record stored, and the continuation ray appended to queue `out`.
-// Workgroups of 1024 threads: the place of a workgroup's continuation rays in the other queue costs
-// ONE atomic add (the counts of its 16 waves are summed in LDS first) -- an add per wave on the one
-// counter took longer than the shading itself.
-constexpr int WF_SHADE_BLOCK = 1024;
+// The place of a workgroup's continuation rays in the other queue costs ONE atomic add (the counts
+// of its waves are summed in LDS first) -- an add per wave on the one counter took longer than the
+// shading itself.  The kernel waits on chains of dependent scattered loads (hit -> triangle ->
+// material), so what pays is waves in flight: workgroups of 512 threads compiled for 6 waves per
+// SIMD (80 registers; three workgroups per CU) are 9 % (room) and 11 % (mis) faster over the whole
+// render in f64 than workgroups of 1024 at the 84 registers the compiler takes unasked (one
+// workgroup per CU); 256 threads are no better in f64 and 8 % slower in f32 (four times the
+// atomic adds), 7 waves per SIMD spill and lose 3 %.
+#ifndef PTX_WF_SHADE_BLOCK
+#define PTX_WF_SHADE_BLOCK 512
+#endif
+#ifndef PTX_WF_SHADE_WAVES
+#define PTX_WF_SHADE_WAVES 6 // waves per SIMD k_wf_shade is compiled for
+#endif
+constexpr int WF_SHADE_BLOCK = PTX_WF_SHADE_BLOCK;
 // CAM: the launch of bounce 0 -- one thread per path of the batch, the hit of its pixel's camera ray.
 // SQ: the scene has square lights (at most 12 lights in all), whose samples need the reference's
 // visibility test: every light with a term gets its slot light x segments + segment of the test
@@ -227,7 +238,7 @@ constexpr int WF_SHADE_BLOCK = 1024;
 // the mark "counts without a test" (length -2) -- with the term beside it, the record's direct half
 // is left to k_wf_gather, which adds the terms in light order once the any-hit launch has run.
 template <class R, bool CAM, bool SQ>
-__global__ void __launch_bounds__(WF_SHADE_BLOCK)
+__global__ void __launch_bounds__(WF_SHADE_BLOCK, PTX_WF_SHADE_WAVES)
     k_wf_shade(DScene<R> S, DBatch B, WfQueue<R> in, WfQueue<R> out, WfQueue<R> tests, WfState<R> W, int bnc)
 {
     __shared__ uint32_t wave_cont[WF_SHADE_BLOCK / 64]; // continuation rays per wave, then their offsets in the workgroup's range
