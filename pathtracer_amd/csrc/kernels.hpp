@@ -320,7 +320,7 @@ template <class R> __device__ __forceinline__ void trav_init(const DScene<R> &S,
     const float P = 0x1p-22f * omax + 0x1p-19f * (3.0f * S.bvh_cmax + omax) + 1e-30f;
     const float big = 1.0e18f; // an axis the ray does not move along: a huge finite slope keeps infinities out of the slabs
     // 1 / d from the f32 reciprocal instruction (1 ulp) of the rounded direction: 1.5 * 2^-23 in
-    // all, well inside the margins by which bvh_step widens every slab
+    // all, well inside the margin that went into P (a quarter of it bounds the roundings)
     T.ivx = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(float(d.x)), -big, big);
     T.ivy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(float(d.y)), -big, big);
     T.ivz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(float(d.z)), -big, big);

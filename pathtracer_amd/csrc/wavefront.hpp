@@ -428,8 +428,11 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, PTX_WF_SHADE_WAVES)
 // the shaded point, as the reference's VisTest runs) with the term beside it -- the
 // next direction, Russian roulette, the continuation ray.  The record's light-sampling half is
 // filled in by k_wf_gather once the any-hit launch has answered the tests.
+#ifndef PTX_WF_SHADE_FAST_WAVES
+#define PTX_WF_SHADE_FAST_WAVES 1 // waves per SIMD k_wf_shade_fast is compiled for (1: what its registers allow, 4 in f64; at 5 / 6 it spills: -6 / -14 % over the whole render)
+#endif
 template <class R, bool CAM>
-__global__ void __launch_bounds__(WF_SHADE_BLOCK)
+__global__ void __launch_bounds__(WF_SHADE_BLOCK, PTX_WF_SHADE_FAST_WAVES)
     k_wf_shade_fast(DScene<R> S, DBatch B, WfQueue<R> in, WfQueue<R> out, WfQueue<R> tests, WfState<R> W, int bnc)
 {
     __shared__ uint32_t wave_cont[WF_SHADE_BLOCK / 64];
