@@ -399,16 +399,28 @@ def cpu_baseline_and_checks(ctx, args, W, H):
     ids = ctx.first_hit()
     oids = O.first_hit()
     gimg, _ = ctx.render(mode=args.mode, spp=spp, seed=13)
-    o2 = oracle.Oracle(ref, seed=14).render(spp=spp, threads=threads) if spp <= 4 else None
     rmse = oracle.rmse_rel(gimg, oimg)
-    floor = oracle.rmse_rel(o2, oimg) if o2 is not None else None
-    # tolerance: max(2 x the oracle's own two-seed noise floor, 1e-3); the floor costs a second CPU
-    # render and is only measured at low spp -- without it the bar is the 1e-3 it can never go below
-    tol = 1e-3 if floor is None else max(2 * floor, 1e-3)
     checks = {"first_hit_mismatches": int((ids != oids).sum()), "first_hit_pixels": int(ids.size),
-              "rmse_vs_cpu_equal_spp": rmse, "spp": spp, "rmse_tolerance": tol,
-              "oracle_two_seed_rmse": floor,
-              "pass": bool((ids == oids).all() and rmse <= tol)}
+              "rmse_vs_cpu_equal_spp": rmse, "spp": spp}
+    if args.mode == "f64":
+        # f64 runs the oracle's arithmetic on the oracle's random numbers: the bar is 1e-9 per pixel, and a
+        # pixel beyond it must be matched, sample by sample, to a named tie alternative of its path
+        # (oracle/parity.py); a bounded number of them is put to that proof here, all of them in the tests
+        from oracle import parity
+        r = parity.check_f64_image(gimg, oimg, ctx, O, range(spp), seed=13, max_pixels=24)
+        checks.update({"f64_pixels_beyond_1e-9": r["beyond"], "put_to_the_proof": r["put_to_the_proof"],
+                       "proven_ties": r["proven_ties"], "unmatched_samples": len(r["unmatched"]),
+                       "largest_difference": r["largest_difference"], "rmse_bar": 1e-4,
+                       "pass": bool((ids == oids).all() and not r["unmatched"] and r["no_sample_differs"] == 0
+                                    and r["proven_ties"] == r["put_to_the_proof"] and rmse < 1e-4)})
+    else:
+        # f32: statistical bar  max(2 x the oracle's own two-seed noise floor, 1e-3); the floor costs a
+        # second CPU render and is only measured at low spp -- without it the bar is the 1e-3 it can never go below
+        o2 = oracle.Oracle(ref, seed=14).render(spp=spp, threads=threads) if spp <= 4 else None
+        floor = oracle.rmse_rel(o2, oimg) if o2 is not None else None
+        tol = 1e-3 if floor is None else max(2 * floor, 1e-3)
+        checks.update({"rmse_tolerance": tol, "oracle_two_seed_rmse": floor,
+                       "pass": bool((ids == oids).all() and rmse <= tol)})
     return cpu, checks
 
 

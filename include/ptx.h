@@ -25,8 +25,15 @@ extern "C" {
 #define PTX_ERR_DEVICE 4   /* HIP error (no device, allocation, launch)                         */
 #define PTX_ERR_STATE 5    /* call order violated (e.g. render before build_accel)              */
 
-#define PTX_MODE_F64 0 /* reference arithmetic: double everywhere, no FMA contraction           */
-#define PTX_MODE_F32 1 /* fast path: float state and tests, statistically equivalent images     */
+/* PTX_MODE_F64: double everywhere.  Camera rays and the ray / triangle test keep the reference's
+ * operation order with no FMA contraction (cMathUtil.cpp:141-163: face ids and hit points are
+ * bit-exact); the shading helpers (samplers, BxDFs, light terms, the clamp) use algebraically
+ * equal, cheaper forms -- rsqrt, sincospi, a Rodrigues rotation, fused multiply-adds -- whose
+ * results differ from a literal evaluation by ulps: per-pixel sums agree with it to 1e-9, except on
+ * paths that meet an exact geometric tie, where an ulp can pick the other of two coincident faces.
+ * PTX_MODE_F32: float state and tests, statistically equivalent images. */
+#define PTX_MODE_F64 0
+#define PTX_MODE_F32 1
 
 /* Which estimator ptx_render runs.  REFERENCE is cPathTracer::RayTracePrimaryRay as written
  * (src/tracing/cPathTracer.cpp:555-704: every light sampled without a weight, the reference's

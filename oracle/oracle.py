@@ -66,6 +66,9 @@ def lib():
         L.orc_closest_hit_probe.restype = C.c_int32
         L.orc_trace_sample.restype = C.c_int32
         L.orc_trace_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_trace_sample_ties.restype = C.c_int32
+        L.orc_trace_sample_ties.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_double,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_vistest.restype = C.c_int
         L.orc_square_light_sample.restype = C.c_double
         L.orc_square_light_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double,
@@ -177,6 +180,42 @@ class Oracle:
         margins = np.full(64, np.inf)
         n = lib().orc_trace_sample(C.byref(self.c), int(x), int(y), int(sample), _p(rgb), _p(faces), _p(margins))
         return rgb, faces[:n].copy(), margins[:n].copy()
+
+    def trace_sample_ties(self, x, y, sample, mask=0, gap=1e-10):
+        """trace_sample with the path's ties falling as `mask` says: a closest-hit search whose
+        winner and runner-up lie within `gap` is a tie, ties are numbered in the order the path
+        meets them, bit k set hands tie k to the runner-up.  Returns (rgb, faces, margins, ties met)."""
+        rgb = np.zeros(3)
+        faces = np.full(64, -2, dtype=np.int32)
+        margins = np.full(64, np.inf)
+        nt = C.c_int32(0)
+        n = lib().orc_trace_sample_ties(C.byref(self.c), int(x), int(y), int(sample), int(mask), float(gap),
+                                        _p(rgb), _p(faces), _p(margins), C.byref(nt))
+        return rgb, faces[:n].copy(), margins[:n].copy(), int(nt.value)
+
+    def tie_alternatives(self, x, y, sample, gap=1e-10, max_ties=6):
+        """Every value the sample can take when the ties on its path fall either way: a list of
+        (mask, rgb, faces).  Mask 0 is the reference's own rule (lowest face id).  A path that meets
+        more than max_ties ties under some mask raises: that is no longer a tie, it is a scene made
+        of them."""
+        out, seen = [], set()
+        pending = [0]
+        while pending:
+            mask = pending.pop()
+            if mask in seen:
+                continue
+            seen.add(mask)
+            rgb, faces, margins, nt = self.trace_sample_ties(x, y, sample, mask, gap)
+            if nt > max_ties:
+                raise AssertionError("pixel (%d, %d) sample %d meets %d ties on one path (mask %#x)" % (y, x, sample, nt, mask))
+            out.append((mask, rgb, faces))
+            # a set bit beyond the ties this path met changes nothing; flipping any tie it met is a new path
+            for k in range(nt):
+                m = (mask & ((1 << (k + 1)) - 1)) ^ (1 << k)
+                # ties after k belong to the path as it ran under `mask`; under m they are met afresh
+                if m not in seen:
+                    pending.append(m)
+        return out
 
     # -- render --------------------------------------------------------------------------------
     def render(self, spp=None, sample_offset=0, spp_total=None, threads=0, stats=False):

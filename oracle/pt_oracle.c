@@ -363,19 +363,62 @@ static inline int ray_box(const orc_bvh_node *nd, const double *o, const double 
  * ulps means the choice hinges on the last bit of the ray (coplanar overlapping faces, shared
  * edges).  The BVH variant culls boxes beyond (1 + 1e-9) of the best distance, so it reports
  * runners-up inside that band exactly and may report a larger value (or infinity) otherwise. */
-static inline void runner_up(double n, const double *dist, double *second)
+/* Tie choice (test diagnostics too): a search whose winner and runner-up lie within `gap` of each
+ * other is a tie -- which of the two a renderer reports hinges on the last ulp of the ray.  Ties are
+ * numbered along a path in the order they are met; bit k of `mask` set makes tie k return the
+ * runner-up (its face, its point) instead of the winner, so that a test can re-trace the path every
+ * way its ties can fall and name the one another renderer took. */
+typedef struct
 {
-    if (n < *dist)
-        *second = *dist; /* the old winner becomes the runner-up */
-    else if (n < *second)
-        *second = n;
+    uint32_t mask;
+    int32_t n;  /* ties met so far */
+    double gap;
+} orc_tie;
+
+typedef struct
+{
+    double dist, pt[3];
+    int32_t face;
+} orc_cand;
+
+/* the reference's order: smaller distance wins, equal distances keep the lower face id (strict '<'
+ * over ascending ids, cAccelStruct.cpp:39-51) */
+static inline int cand_before(double n, int32_t f, const orc_cand *c)
+{
+    return n < c->dist || (n == c->dist && f < c->face);
+}
+
+static inline void cand_offer(orc_cand *best, orc_cand *snd, double n, int32_t f, const double *p)
+{
+    orc_cand c = {n, {p[0], p[1], p[2]}, f};
+    if (best->face < 0 || cand_before(n, f, best))
+    {
+        *snd = *best;
+        *best = c;
+    }
+    else if (snd->face < 0 || cand_before(n, f, snd))
+        *snd = c;
+}
+
+static int32_t cand_result(orc_cand *best, const orc_cand *snd, double *pt, double *second, orc_tie *tie)
+{
+    if (second)
+        *second = (best->face < 0 || snd->face < 0) ? INFINITY : snd->dist;
+    if (tie && best->face >= 0 && snd->face >= 0 && snd->dist - best->dist <= tie->gap)
+    {
+        int32_t k = tie->n++;
+        if (k < 32 && ((tie->mask >> k) & 1u))
+            *best = *snd;
+    }
+    if (best->face >= 0)
+        pt[0] = best->pt[0], pt[1] = best->pt[1], pt[2] = best->pt[2];
+    return best->face;
 }
 
 static int32_t closest_brute(const orc_scene *sc, const double *o, const double *d, double *pt,
-                             orc_stats *st, double *second)
+                             orc_stats *st, double *second, orc_tie *tie)
 {
-    int32_t target = -1;
-    double dist = 1.7976931348623157e308, snd = INFINITY;
+    orc_cand best = {1.7976931348623157e308, {NAN, NAN, NAN}, -1}, snd = best;
     pt[0] = pt[1] = pt[2] = NAN;
     for (int32_t f = 0; f < sc->n_tris; f++)
     {
@@ -389,25 +432,17 @@ static int32_t closest_brute(const orc_scene *sc, const double *o, const double 
             continue;
         double e[3] = {p[0] - o[0], p[1] - o[1], p[2] - o[2]};
         double n = norm3(e);
+        /* ascending ids: cand_before() is the reference's  n < dist  here */
         if (n > 1e-6)
-            runner_up(n, &dist, &snd);
-        if (n < dist && n > 1e-6)
-        {
-            pt[0] = p[0], pt[1] = p[1], pt[2] = p[2];
-            dist = n;
-            target = f;
-        }
+            cand_offer(&best, &snd, n, f, p);
     }
-    if (second)
-        *second = target < 0 ? INFINITY : (snd > 1e308 ? INFINITY : snd);
-    return target;
+    return cand_result(&best, &snd, pt, second, tie);
 }
 
 static int32_t closest_bvh(const orc_scene *sc, const double *o, const double *d, double *pt,
-                           orc_stats *st, double *second)
+                           orc_stats *st, double *second, orc_tie *tie)
 {
-    int32_t target = -1;
-    double dist = 1.7976931348623157e308, snd = INFINITY;
+    orc_cand best = {1.7976931348623157e308, {NAN, NAN, NAN}, -1}, snd = best;
     pt[0] = pt[1] = pt[2] = NAN;
     int32_t stack[128];
     int sp = 0;
@@ -418,7 +453,7 @@ static int32_t closest_bvh(const orc_scene *sc, const double *o, const double *d
     while (sp)
     {
         const orc_bvh_node *nd = &g_bvh_nodes[stack[--sp]];
-        if (!ray_box(nd, o, d, dist * per_len * (1 + 1e-9) + 1e-9))
+        if (!ray_box(nd, o, d, best.dist * per_len * (1 + 1e-9) + 1e-9))
             continue;
         if (nd->left < 0)
         {
@@ -434,15 +469,9 @@ static int32_t closest_bvh(const orc_scene *sc, const double *o, const double *d
                     continue;
                 double e[3] = {p[0] - o[0], p[1] - o[1], p[2] - o[2]};
                 double n = norm3(e);
-                if (n > 1e-6)
-                    runner_up(n, &dist, &snd);
                 /* same winner as the ascending-id strict-'<' loop: smaller dist, ties -> lower id */
-                if (n > 1e-6 && (n < dist || (n == dist && f < target)))
-                {
-                    pt[0] = p[0], pt[1] = p[1], pt[2] = p[2];
-                    dist = n;
-                    target = f;
-                }
+                if (n > 1e-6)
+                    cand_offer(&best, &snd, n, f, p);
             }
         }
         else if (sp + 2 <= 128)
@@ -451,34 +480,32 @@ static int32_t closest_bvh(const orc_scene *sc, const double *o, const double *d
             stack[sp++] = nd->right;
         }
     }
-    if (second)
-        *second = target < 0 ? INFINITY : (snd > 1e308 ? INFINITY : snd);
-    return target;
+    return cand_result(&best, &snd, pt, second, tie);
 }
 
 int32_t orc_closest_hit(const orc_scene *sc, const double *o, const double *d, double *pt)
 {
     if (sc->use_bvh && g_bvh_nodes)
-        return closest_bvh(sc, o, d, pt, NULL, NULL);
-    return closest_brute(sc, o, d, pt, NULL, NULL);
+        return closest_bvh(sc, o, d, pt, NULL, NULL, NULL);
+    return closest_brute(sc, o, d, pt, NULL, NULL, NULL);
 }
 
-/* closest hit plus the runner-up distance (see runner_up above) */
+/* closest hit plus the runner-up's distance (the tie probe above) */
 int32_t orc_closest_hit_probe(const orc_scene *sc, const double *o, const double *d, double *pt, double *second)
 {
     if (sc->use_bvh && g_bvh_nodes)
-        return closest_bvh(sc, o, d, pt, NULL, second);
-    return closest_brute(sc, o, d, pt, NULL, second);
+        return closest_bvh(sc, o, d, pt, NULL, second, NULL);
+    return closest_brute(sc, o, d, pt, NULL, second, NULL);
 }
 
 static int32_t closest(const orc_scene *sc, const double *o, const double *d, double *pt,
-                       orc_stats *st, double *second)
+                       orc_stats *st, double *second, orc_tie *tie)
 {
     if (st)
         st->closest_rays++;
     if (sc->use_bvh && g_bvh_nodes)
-        return closest_bvh(sc, o, d, pt, st, second);
-    return closest_brute(sc, o, d, pt, st, second);
+        return closest_bvh(sc, o, d, pt, st, second, tie);
+    return closest_brute(sc, o, d, pt, st, second, tie);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -964,7 +991,7 @@ void orc_first_hit(const orc_scene *sc, int32_t *ids, double *pts)
             size_t id = (size_t)y * sc->width + x;
             double o[3], d[3], p[3];
             primary_ray(sc, mat, x, y, o, d);
-            ids[id] = closest(sc, o, d, p, NULL, NULL);
+            ids[id] = closest(sc, o, d, p, NULL, NULL, NULL);
             if (pts)
                 pts[id * 3] = p[0], pts[id * 3 + 1] = p[1], pts[id * 3 + 2] = p[2];
         }
@@ -982,6 +1009,7 @@ typedef struct
     int32_t n;
     int32_t face[ORC_MAX_DEPTH];
     double margin[ORC_MAX_DEPTH];
+    orc_tie tie; /* which way the ties of this path fall (mask 0: the reference's own rule) */
 } orc_probe;
 
 /* one iteration of the sample loop (cPathTracer.cpp:578-693): final = the sample's radiance after
@@ -1003,7 +1031,7 @@ static void trace_sample(const orc_scene *sc, const double *o0, const double *d0
         double p[3], second = INFINITY;
         if (st)
             st->segments++;
-        int32_t f = closest(sc, o, d, p, st, probe ? &second : NULL);
+        int32_t f = closest(sc, o, d, p, st, probe ? &second : NULL, probe ? &probe->tie : NULL);
         if (probe)
         {
             double e[3] = {p[0] - o[0], p[1] - o[1], p[2] - o[2]};
@@ -1293,7 +1321,7 @@ static void fast_sample(const orc_scene *sc, const double *o0, const double *d0,
         double p[3], second = INFINITY;
         if (st)
             st->segments++;
-        int32_t f = closest(sc, o, d, p, st, probe ? &second : NULL);
+        int32_t f = closest(sc, o, d, p, st, probe ? &second : NULL, probe ? &probe->tie : NULL);
         double t_geom = INFINITY;
         if (f >= 0)
         {
@@ -1440,12 +1468,15 @@ static void trace_pixel(const orc_scene *sc, const double *mat, int x, int y, do
 
 /* One sample of one pixel with its diagnostics (tests only): rgb = the sample's radiance (not yet
  * divided by the sample count); faces / margins: [depth] per-bounce face hit and winning margin.
- * Returns the number of bounces traced. */
-int32_t orc_trace_sample(const orc_scene *sc, int x, int y, int sample, double *rgb, int32_t *faces,
-                         double *margins)
+ * Closest-hit searches whose winner and runner-up lie within `gap` are the path's ties, numbered as
+ * they are met; bit k of tie_mask makes tie k fall to the runner-up; *n_ties receives how many the
+ * path (as traced under this mask) met.  Returns the number of bounces traced. */
+int32_t orc_trace_sample_ties(const orc_scene *sc, int x, int y, int sample, uint32_t tie_mask, double gap,
+                              double *rgb, int32_t *faces, double *margins, int32_t *n_ties)
 {
     double mat[16], o0[3], d0[3];
     orc_probe pr;
+    pr.tie.mask = tie_mask, pr.tie.n = 0, pr.tie.gap = gap;
     orc_camera_matrix(sc, mat);
     primary_ray(sc, mat, x, y, o0, d0);
     if (sc->estimator == 1)
@@ -1459,7 +1490,16 @@ int32_t orc_trace_sample(const orc_scene *sc, int x, int y, int sample, double *
         if (margins)
             margins[i] = pr.margin[i];
     }
+    if (n_ties)
+        *n_ties = pr.tie.n;
     return pr.n;
+}
+
+/* the same with every tie falling the reference's way */
+int32_t orc_trace_sample(const orc_scene *sc, int x, int y, int sample, double *rgb, int32_t *faces,
+                         double *margins)
+{
+    return orc_trace_sample_ties(sc, x, y, sample, 0u, -1.0, rgb, faces, margins, NULL);
 }
 
 /* the final per-pixel clamp (cPathTracer.cpp:701-702) */

@@ -46,13 +46,14 @@ def room_scene():
 
 def pytest_terminal_summary(terminalreporter):
     """f64 image comparisons of the GPU parity tests: how many pixels differed beyond the bar (each
-    one was re-traced and shown to hinge on a closest-hit tie, or the test failed)."""
+    sample of each was re-traced by the oracle and equals a named tie alternative of its path, or the
+    test failed)."""
     mod = sys.modules.get("test_gpu_parity")
     rows = getattr(mod, "OUTLIERS", None) if mod else None
     if rows:
         total = sum(r[1] for r in rows)
-        terminalreporter.write_line("f64 parity: %d image comparisons, %d pixels beyond 1e-9 in all (every one a proven tie):"
+        terminalreporter.write_line("f64 parity: %d image comparisons, %d pixels beyond 1e-9 in all (every one matched to a named tie alternative):"
                                     % (len(rows), total))
-        for name, bad, n in rows:
+        for name, bad, n, proven in rows:
             if bad:
-                terminalreporter.write_line("  %s: %d of %d pixels" % (name, bad, n))
+                terminalreporter.write_line("  %s: %d of %d pixels, %d proven" % (name, bad, n, proven))

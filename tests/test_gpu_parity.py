@@ -12,51 +12,41 @@ import numpy as np
 import pytest
 
 import pathtracer_amd as pt
-from oracle import oracle, scene_io
+from oracle import oracle, parity, scene_io
 
 pytestmark = pytest.mark.gpu
-F64_TOL = 1e-9
+F64_TOL = parity.F64_TOL
 
 
-TIE_GAP = 1e-10      # two closest-hit candidates nearer to each other than this are a tie (scene units of 1 to 10)
-OUTLIERS = []        # (test id, differing pixels, pixels) of every comparison, printed at the end of the session
+OUTLIERS = []        # (test id, differing pixels, pixels, proven ties) of every comparison, printed at the end of the session
 
 
 def assert_f64_parity(img, oimg, st=None, ost=None, depth=15, ctx=None, O=None, spp=None, origin=(0, 0),
                       sample_offset=0, render_kw=None):
     """f64 images must agree to F64_TOL in every pixel -- except where the path hinges on an exact
-    geometric tie, and every exception is PROVEN to be one: for each differing pixel, each of its
-    samples is rendered alone on the GPU (through the C ABI) and re-traced by the oracle; a sample
-    whose two values differ must contain a closest-hit search in the oracle's path whose winner and
-    runner-up are within TIE_GAP of each other (the Cornell box asset has two coplanar, oppositely
-    wound quads in the ceiling; which of them wins is decided by the last ulp of the ray direction,
-    where the device's and glibc's sin / cos / acos may differ -- a different, equally valid
-    sample).  Without ctx and O no exception is allowed at all.  origin: (row, column) of img[0, 0]
-    in the frame ctx renders.  Returns the number of differing pixels."""
+    geometric tie, and every exception is MATCHED to one (oracle/parity.py): for each differing
+    pixel, each of its samples is rendered alone on the GPU (through the C ABI) and re-traced by the
+    oracle; a sample whose two values differ must equal, to F64_TOL, the oracle's value with the
+    closest-hit ties on its path (winner and runner-up within 1e-10) falling another, named way.
+    That a tie exists on the path is not enough.  Without ctx and O no exception is allowed at
+    all.  origin: (row, column) of img[0, 0] in the frame ctx renders.  Returns the number of
+    differing pixels."""
     img, oimg = np.asarray(img), np.asarray(oimg)
-    diff = np.abs(img - oimg).max(axis=-1)
-    bad = np.argwhere(diff > F64_TOL)
+    bad, diff = parity.outliers(img, oimg)
     n_bad = len(bad)
-    OUTLIERS.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], n_bad, int(diff.size)))
+    proven = 0
     if n_bad:
         assert ctx is not None and O is not None, "%d of %d pixels differ by more than %g" % (n_bad, diff.size, F64_TOL)
         n_spp = int(spp if spp is not None else O.c.spp)
         # a guard against proving thousands of pixels one by one (about 1 path in 2000 meets a tie in the Cornell box)
         assert n_bad <= max(2, diff.size * n_spp // 500), "%d of %d pixels differ: too many to be ties" % (n_bad, diff.size)
-        for r, c in bad:
-            y, x = int(r) + origin[0], int(c) + origin[1]
-            explained = 0.0
-            for s in range(sample_offset, sample_offset + n_spp):
-                one, _ = ctx.render(mode="f64", spp=1, sample_offset=s, spp_total=1, rows=(y, y + 1), seed=int(O.c.seed),
-                                    **(render_kw or {}))
-                rgb, faces, margins = O.trace_sample(x, y, s)
-                d = np.abs(one[y, x] - rgb).max()
-                if d > F64_TOL:
-                    assert margins.size and margins.min() <= TIE_GAP, \
-                        "pixel (%d, %d) sample %d differs by %g without a tie on its path (smallest margin %g, faces %s)" % (
-                            y, x, s, d, margins.min() if margins.size else np.inf, faces.tolist())
-                    explained += d
-            assert explained > 0, "pixel (%d, %d) differs by %g but none of its samples does" % (y, x, diff[r, c])
+        r = parity.prove_pixels(ctx, O, [(int(y) + origin[0], int(x) + origin[1]) for y, x in bad],
+                                range(sample_offset, sample_offset + n_spp), seed=int(O.c.seed), render_kw=render_kw)
+        assert not r["unmatched"], "samples that differ from the oracle and equal no tie alternative of their path: %s" % (r["unmatched"][:3],)
+        assert r["no_sample_differs"] == 0, "%d pixels differ although none of their samples does" % r["no_sample_differs"]
+        proven = r["proven_ties"]
+        assert proven == n_bad
+    OUTLIERS.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], n_bad, int(diff.size), proven))
     assert oracle.rmse_rel(img, oimg) < 1e-4
     if st is not None:
         assert st["paths"] == ost["paths"]

@@ -207,6 +207,41 @@ def test_closest_hit_ties_keep_lowest_face_id(cbox):
     assert f != 6 and f != 7
 
 
+def test_tie_alternatives_name_every_way_a_path_can_fall(root):
+    """The tie choice behind the f64 parity rule (oracle/parity.py): mask 0 is the reference's own
+    path; bit k hands the k-th tie of the path to the runner-up, which changes the face reported
+    there and everything after it; a path without ties has one alternative -- itself."""
+    from oracle import parity
+    sc = scene_io.load_conf(os.path.join(root, "config/cbox.conf"), root_dir=root, width=64, height=64, spp=8)
+    O = oracle.Oracle(sc, seed=13)
+    # (column, row, sample) of paths that cross the coplanar ceiling quads, found by scanning the frame once
+    for x, y, s in ((16, 18, 5), (14, 29, 1), (51, 49, 7)):
+        rgb0, faces0, margins0, nt = O.trace_sample_ties(x, y, s, 0)
+        plain, pfaces, pmargins = O.trace_sample(x, y, s)
+        assert np.array_equal(rgb0, plain) and np.array_equal(faces0, pfaces)          # mask 0 = the reference's rule
+        assert nt == 1 and margins0.min() <= parity.TIE_GAP
+        k = int(np.argmin(margins0))
+        rgb1, faces1, _, nt1 = O.trace_sample_ties(x, y, s, 1)
+        assert np.array_equal(faces1[:k], faces0[:k]) and faces1[k] != faces0[k]       # the other face at the tie
+        assert np.abs(rgb1 - rgb0).max() > 1e-6                                        # and another sample value
+        alts = O.tie_alternatives(x, y, s)
+        assert sorted(m for m, _, _ in alts)[:2] == [0, 1] and len(alts) == 1 + max(1, nt1)
+        # the matching rule: the oracle's other path is accepted as a tie, its own as equal, anything else is not
+        assert parity.match_sample(rgb0, O, x, y, s)[0] == "equal"
+        assert parity.match_sample(rgb1, O, x, y, s)[:2] == ("tie", 1)
+        assert parity.match_sample(0.5 * (rgb0 + rgb1), O, x, y, s)[0] == "unmatched"
+    rgb, faces, margins, nt = O.trace_sample_ties(30, 40, 0, 0)
+    assert nt == 0 and len(O.tie_alternatives(30, 40, 0)) == 1
+    assert parity.match_sample(rgb + 1e-6, O, 30, 40, 0)[0] == "unmatched"             # no tie: nothing excuses a difference
+    # a bit beyond the ties a path meets changes nothing
+    assert np.array_equal(O.trace_sample_ties(30, 40, 0, 0xff)[0], rgb)
+    # the oracle's culling tree reports the same ties as its plain loop
+    Ob = oracle.Oracle(sc, seed=13, use_bvh=True)
+    for m in (0, 1):
+        a, b = O.trace_sample_ties(16, 18, 5, m), Ob.trace_sample_ties(16, 18, 5, m)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[3] == b[3]
+
+
 def test_vistest_semantics(cbox):
     O = oracle.Oracle(cbox)
     light_pt = (2.78, 5.48, 2.795)

@@ -1,9 +1,10 @@
 """The headline configuration at its full size against the CPU oracle: config/cbox.conf at
 1024 x 1024 with 256 samples per pixel (2.7e8 paths) rendered in f64 on the GPU and by the oracle
 (all host threads), compared pixel by pixel.  Pixels beyond 1e-9 are counted, and a sample of them is
-put through the proof the parity tests use: every sample of the pixel is rendered alone on the GPU
-and re-traced by the oracle, and where the two differ the oracle's path must contain a closest-hit
-search whose two best candidates are within 1e-10 of each other (a tie).  Prints one JSON line.
+put through the proof the parity tests use (oracle/parity.py): every sample of the pixel is rendered
+alone on the GPU and re-traced by the oracle, and where the two differ the GPU's value must equal the
+oracle's with the closest-hit ties of that path (two best candidates within 1e-10) falling another,
+named way.  Prints one JSON line.
 
     python tools/full_frame_parity.py [--spp 256] [--size 1024] [--prove 40] [--conf config/mis.conf --width 768 --height 512]
 """
@@ -69,35 +70,23 @@ def main():
            "rmse_rel": float(oracle.rmse_rel(img, oimg))}
     ref.region = (0, 0, H - 1, W - 1)
     O = oracle.Oracle(ref, seed=13)
-    proven = unexplained = 0
+    from oracle import parity
     pick = bad[np.random.default_rng(13).permutation(len(bad))[: a.prove]] if len(bad) else np.zeros((0, 2), dtype=np.int64)
+    proven = unexplained = 0
     if len(pick):
         dev = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
-        by_row = {}
-        for y, x in pick:
-            by_row.setdefault(int(y), []).append(int(x))
-        done = 0
-        for y, xs in sorted(by_row.items()):
-            differs = {x: False for x in xs}
-            ok = {x: True for x in xs}
-            for smp in range(a.spp):
-                # the row's pixels, this sample alone (one launch, one row copied back)
-                c.render_device(dev.data_ptr(), mode="f64", spp=1, sample_offset=smp, spp_total=1, rows=(y, y + 1), seed=13)
-                row = dev[y].cpu().numpy()
-                for x in xs:
-                    rgb, faces, margins = O.trace_sample(x, y, smp)
-                    if np.abs(row[x] - rgb).max() > TOL:
-                        differs[x] = True
-                        ok[x] = ok[x] and bool(margins.size and margins.min() <= TIE_GAP)
-            for x in xs:
-                if differs[x] and ok[x]:
-                    proven += 1
-                else:
-                    unexplained += 1
-                    print("pixel (%d, %d): NOT EXPLAINED" % (y, x), file=sys.stderr, flush=True)
-            done += len(xs)
-            if done % 50 < len(xs):
-                print("%d of %d pixels put to the proof" % (done, len(pick)), file=sys.stderr, flush=True)
+
+        def render_row(y, smp):
+            # the row's pixels, this sample alone (one launch, one row copied back)
+            c.render_device(dev.data_ptr(), mode="f64", spp=1, sample_offset=smp, spp_total=1, rows=(y, y + 1), seed=13)
+            return dev[y].cpu().numpy()
+
+        r = parity.prove_pixels(c, O, [(int(y), int(x)) for y, x in pick], range(a.spp), seed=13, render_row=render_row)
+        proven = r["proven_ties"]
+        unexplained = len(pick) - proven
+        for y, x, smp, detail in r["unmatched"][:20]:
+            print("pixel (%d, %d) sample %d: NOT MATCHED %s" % (y, x, smp, detail), file=sys.stderr, flush=True)
+        rec.update(tie_samples=r["tie_samples"], unmatched_samples=len(r["unmatched"]), pixels_no_sample_differs=r["no_sample_differs"])
     rec.update(pixels_put_to_the_proof=int(len(pick)), proven_ties=proven, not_explained=unexplained)
     print(json.dumps(rec), flush=True)
     return 0 if unexplained == 0 else 1

@@ -2,10 +2,11 @@
 geometry thrown in (free triangles, tilted and axis-aligned quads, slivers, fans; random materials
 out of the box's own -- diffuse, glossy, glass, emitter -- flat or interpolated normals) and random
 extra lights (spheres, a second square).  f64 renders must equal the oracle's at 1e-9 per pixel, every
-exception a proven closest-hit tie (the rule of tests/test_gpu_parity.py), for both estimators,
+exception matched to a named tie alternative of its path (the rule of oracle/parity.py), for both estimators,
 with the BVH and -- up to 64 faces -- with the all-triangles intersector.  A scene whose random quads
 coincide with a wall trips the guards of that rule (many tie pixels in a 24 x 24 frame): it is then
-put through the proof sample by sample (prove_all) and fails only on a sample without a tie.
+put through the proof sample by sample (prove_all) and fails only on a sample that equals none of
+the values its path can take.
 
     python tools/fuzz_render.py [--seeds 30] [--first 0]
 """
@@ -89,34 +90,19 @@ def scene(seed, template):
 
 
 def prove_all(c, O, ref, est, img, oimg, st, ost, seed=13, verbose=False):
-    """The tie proof of tests/test_gpu_parity.py without its guards (number of differing pixels, rMSE
-    of the frame, segment counts), for scenes full of coincident faces: every sample of every pixel
-    that differs -- of every pixel at all when only the segment counts differ -- is rendered alone
-    and re-traced by the oracle.  Returns (samples that differ without a tie on their path, samples
-    that differ with one, samples with a tie on their path that agree all the same)."""
+    """The proof of oracle/parity.py without the test helper's guards (number of differing pixels,
+    rMSE of the frame, segment counts), for scenes full of coincident faces: every sample of every
+    pixel that differs -- of every pixel at all when only the segment counts differ -- is rendered
+    alone and matched against the oracle's path or a named tie alternative of it.  Returns (samples
+    that equal no alternative, samples that equal one, samples with a tie on their path that agree
+    all the same)."""
+    from oracle import parity
     diff = np.abs(img - oimg).max(axis=-1)
     everywhere = int(st["segments"]) != int(ost["segments"])
-    unexplained = explained = silent = 0
-    for y in range(ref.height):
-        for x in range(ref.width):
-            if diff[y, x] <= 1e-9 and not everywhere:
-                continue
-            for smp in range(ref.spp):
-                one, _ = c.render(mode="f64", spp=1, sample_offset=smp, spp_total=1, rows=(y, y + 1), seed=seed, estimator=est)
-                rgb, faces, margins = O.trace_sample(x, y, smp)
-                d = np.abs(one[y, x] - rgb).max()
-                tie = bool(margins.size and margins.min() <= 1e-10)
-                if d > 1e-9:
-                    if tie:
-                        explained += 1
-                    else:
-                        unexplained += 1
-                elif tie:
-                    silent += 1
-                if verbose and (d > 1e-9 or tie):
-                    print("  pixel (%d, %d) sample %d: differs by %.3g, smallest margin %.3g, faces %s%s" % (
-                        y, x, smp, d, margins.min() if margins.size else np.inf, faces.tolist(), "" if tie or d <= 1e-9 else "  <-- NO TIE"), flush=True)
-    return unexplained, explained, silent
+    pixels = [(y, x) for y in range(ref.height) for x in range(ref.width) if everywhere or diff[y, x] > parity.F64_TOL]
+    r = parity.prove_pixels(c, O, pixels, range(ref.spp), seed=seed, render_kw=dict(estimator=est),
+                            verbose=(lambda m: print("  " + m, flush=True)) if verbose else None)
+    return len(r["unmatched"]), r["tie_samples"], r["silent_ties"]
 
 
 def main():
@@ -152,11 +138,11 @@ def main():
                     # without the guards tells which
                     un, ex, si = prove_all(c, O, ref, est, img, oimg, st, ost)
                     if un == 0 and (ex > 0 or si > 0):
-                        notes.append("%s/%s: beyond the helper's guards, all ties (%d samples differ on a proven tie, %d more meet one and agree)" % (
+                        notes.append("%s/%s: beyond the helper's guards, all ties (%d samples equal a named tie alternative, %d more meet a tie and agree)" % (
                             est, c.last_kernel(), ex, si))
                     else:
                         failures += 1
-                        notes.append("%s/%s FAILED: %s (%d samples differ without a tie)" % (est, c.last_kernel(), str(e)[:300], un))
+                        notes.append("%s/%s FAILED: %s (%d samples equal no alternative)" % (est, c.last_kernel(), str(e)[:300], un))
         print("seed %d: %d faces, %d lights, depth %d, %d spp%s" % (seed, ref.verts.shape[0], ref.lights.shape[0], ref.depth, ref.spp,
                                                                    "".join("; " + x for x in notes)), flush=True)
     for k in sorted(kernels):
