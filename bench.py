@@ -145,6 +145,9 @@ def main():
     ap.add_argument("--no-fast-estimator", action="store_true",
                     help="skip the one step of the physically based estimator that is run for the record (profiling sessions: "
                          "the wavefront tracer's traversal kernel serves both estimators, and counters are summed per kernel)")
+    ap.add_argument("--estimator", default="reference", choices=["reference", "fast"],
+                    help="the estimator of the timed steps: the reference's own (the metric) or the physically based one "
+                         "(profiling sessions of its kernels; the line then says so in config.estimator)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--scheme", default="samples", choices=["samples", "bands"],
                     help="multi-GPU sharding: 'samples' = every rank renders --spp samples of every pixel (weak "
@@ -210,7 +213,8 @@ def main():
         # frame (the rest of `out` stays zero); then RCCL reduce(sum) -> rank 0
         return render_frame(render_fn, out, spp_total, rank, world, scheme=args.scheme, reduce=reduce and use_dist,
                             collective=use_dist,
-                            mode=mode or args.mode, seed=13, profile=profile)
+                            mode=mode or args.mode, seed=13, profile=profile,
+                            **({"estimator": "fast"} if args.estimator == "fast" else {}))
 
     def fence():
         if use_dist:
@@ -324,7 +328,7 @@ def main():
         # the physically based estimator on the same frame, one step, for the record (another
         # estimator: its paths are shorter and every light costs a visibility test; not the metric)
         fast = None
-        if world == 1 and not args.no_fast_estimator:
+        if world == 1 and not args.no_fast_estimator and args.estimator != "fast":
             render_fn(out, spp=1, sample_offset=0, spp_total=1, mode=args.mode, seed=13, estimator="fast")   # its kernel and state, untimed
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -336,7 +340,7 @@ def main():
 
         cpu = None
         checks = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.estimator == "reference":
             cpu, checks = cpu_baseline_and_checks(ctx, args, W, H)
 
         result = {
@@ -349,7 +353,7 @@ def main():
                                    % (scene_name, W, H, args.spp, info.depth, info.n_tris, info.n_lights, info.n_square_lights,
                                       args.conf, ", the headline configuration" if headline else ""),
                        "intersector": "all-triangles (plane records)" if ctx.accel_info()["brute_force"] else "BVH",
-                       "tracer_kernel": ran, "state_bytes": int(ps["state_bytes"]),
+                       "tracer_kernel": ran, "state_bytes": int(ps["state_bytes"]), "estimator": args.estimator,
                        "global_spp": spp_total, "paths_per_step": paths_per_step,
                        "sharding": ("sample ranges per rank" if args.scheme == "samples" else "interleaved row bands of 8 per rank")
                                    + " + RCCL reduce(sum) of the radiance sums to rank 0"},

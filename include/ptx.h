@@ -177,7 +177,8 @@ void ptx_context_destroy(ptx_context *);
  * and path where lights need visibility tests), "wf_refill" (1..64: idle lanes at which a wave of that traversal kernel takes
  * new rays; default 24), "lds_nodes" (BVH scenes: at most this many of the tree's first -- busiest
  * -- node records in LDS behind the stack levels; -1 = what fits next to 16 stack levels, 0 = none),
- * "raycast_wavefront" (1/0, a timing aid: ptx_raycast of unit-length directions through the
+ * "bvh_split" (0..400, default 0: reference splitting in the BVH builder, at most this many extra
+ * triangle references per 100 triangles), "raycast_wavefront" (1/0, a timing aid: ptx_raycast of unit-length directions through the
  * wavefront tracer's traversal kernel).  Results do not depend on any of
  * them.  Set before
  * ptx_build_accel. */

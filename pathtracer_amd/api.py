@@ -113,10 +113,11 @@ class Scene:
         check(_lib.lib().ptx_scene_plane_records(self._h, _ptr(n[0:1]), _ptr(n[1:2]), _ptr(rec_tri), _ptr(blockers)))
         return int(n[0]), int(n[1]), rec_tri, blockers
 
-    def bvh_check(self, median=False):
-        """Builds the 4-wide BVH on the host and checks its invariants (no GPU needed)."""
+    def bvh_check(self, median=False, split=False):
+        """Builds the 4-wide BVH on the host and checks its invariants (no GPU needed).  median: median
+        splits instead of SAH; split: SAH with reference splitting (the option "bvh_split" at 30)."""
         info = np.zeros(6, dtype=np.int64)
-        check(_lib.lib().ptx_scene_bvh_check(self._h, 1 if median else 0, _ptr(info)))
+        check(_lib.lib().ptx_scene_bvh_check(self._h, 1 if median else (2 if split else 0), _ptr(info)))
         return dict(n_nodes=int(info[0]), n_children=int(info[1]), max_depth=int(info[2]), stack_need=int(info[3]),
                     triangle_refs=int(info[4]), violations=int(info[5]))
 

@@ -56,11 +56,14 @@ struct Node2
     int32_t c0, c1; // >= 0: node index; < 0: leaf, ~c = (first << 3) | (count - 1)
 };
 
+// A reference: one triangle, or the part of one that lies in `box` (reference splitting below).
+// The builder only ever sees references: boxes and box centres.
 struct Builder
 {
     const float *verts;
-    std::vector<Box> tri_box;
-    std::vector<double> centroid; // [F][3]
+    std::vector<Box> tri_box;     // [references]
+    std::vector<double> centroid; // [references][3]
+    std::vector<int32_t> ref_tri; // [references] the triangle a reference belongs to
     std::vector<int32_t> order;
     std::vector<Node2> nodes;
     bool median = false;
@@ -206,6 +209,175 @@ struct Builder
         return ~static_cast<int32_t>((first << 3) | (count - 1));
     }
 };
+
+
+// ---------------------------------------------------------------------------------------------
+// Reference splitting before the build.  A large triangle among small ones (a wall behind
+// furniture) has a box that overlaps everything in front of it, and every ray through that space
+// visits the triangle's leaf.  So the triangles with the emptiest boxes are cut -- not the
+// geometry, only the REFERENCES: a reference is a convex polygon (the triangle clipped to a box),
+// it is cut by an axis plane into two polygons, and each half goes into the tree with the box of
+// its own polygon.  The tree then holds some triangles in several leaves; the intersector tests
+// the whole triangle wherever it meets it, so hits, distances and ties are those of the unsplit
+// tree (the same triangle found twice is the same hit).  Which reference is cut next: the one with
+// the largest  box area - 2 x (sum of the polygon's three axis projections)  -- the surface its box
+// has beyond what a flat polygon needs.  Where: the coarsest plane of a power-of-two grid over the
+// scene box that crosses it (neighbouring references are cut by the same planes and their halves
+// line up).  The number of extra references is bounded (`budget`).
+// ---------------------------------------------------------------------------------------------
+struct Poly
+{
+    int n = 0;
+    double p[10][3]; // a triangle clipped by six planes has at most nine corners
+    Box box() const
+    {
+        Box b;
+        for (int i = 0; i < n; i++)
+            b.grow(p[i]);
+        return b;
+    }
+    // twice the sum of the polygon's areas projected along the three axes
+    double proj2() const
+    {
+        double a[3] = {0, 0, 0};
+        for (int i = 1; i + 1 < n; i++)
+        {
+            const double u[3] = {p[i][0] - p[0][0], p[i][1] - p[0][1], p[i][2] - p[0][2]};
+            const double v[3] = {p[i + 1][0] - p[0][0], p[i + 1][1] - p[0][1], p[i + 1][2] - p[0][2]};
+            a[0] += u[1] * v[2] - u[2] * v[1];
+            a[1] += u[2] * v[0] - u[0] * v[2];
+            a[2] += u[0] * v[1] - u[1] * v[0];
+        }
+        return std::fabs(a[0]) + std::fabs(a[1]) + std::fabs(a[2]);
+    }
+    // the part on the side `keep_low ? x[axis] <= c : x[axis] >= c` (closed: a corner in the plane belongs to both)
+    Poly clip(int axis, double c, bool keep_low) const
+    {
+        Poly out;
+        for (int i = 0; i < n; i++)
+        {
+            const double *a = p[i], *b = p[(i + 1) % n];
+            const double da = keep_low ? a[axis] - c : c - a[axis], db = keep_low ? b[axis] - c : c - b[axis];
+            if (da <= 0 && out.n < 10)
+                std::memcpy(out.p[out.n++], a, sizeof(double) * 3);
+            if ((da < 0 && db > 0) || (da > 0 && db < 0))
+            {
+                const double t = da / (da - db);
+                double q[3];
+                for (int k = 0; k < 3; k++)
+                    q[k] = a[k] + t * (b[k] - a[k]);
+                q[axis] = c;
+                if (out.n < 10)
+                    std::memcpy(out.p[out.n++], q, sizeof(double) * 3);
+            }
+        }
+        return out;
+    }
+};
+
+struct SplitRef
+{
+    Poly poly;
+    Box box;
+    int32_t tri;
+    double priority;
+};
+
+double split_priority(const SplitRef &r)
+{
+    return r.box.area() - r.poly.proj2();
+}
+
+// the coarsest plane of the power-of-two grid over [lo, hi] of the scene that lies strictly inside (a, b)
+bool grid_plane(double lo, double hi, double a, double b, double &plane, int &level)
+{
+    if (!(hi > lo) || !(b > a))
+        return false;
+    const double ua = (a - lo) / (hi - lo), ub = (b - lo) / (hi - lo);
+    for (level = 1; level <= 40; level++)
+    {
+        const double cells = std::ldexp(1.0, level);
+        const double k = std::floor(ua * cells) + 1; // first plane above a
+        const double c = lo + (hi - lo) * (k / cells);
+        if (c > a && c < b)
+        {
+            plane = c;
+            return true;
+        }
+    }
+    return false;
+}
+
+void split_references(const float *verts, int n_tris, double budget, std::vector<SplitRef> &refs)
+{
+    refs.resize(n_tris);
+    Box scene;
+    for (int f = 0; f < n_tris; f++)
+    {
+        SplitRef &r = refs[f];
+        r.poly.n = 3;
+        for (int j = 0; j < 3; j++)
+            for (int k = 0; k < 3; k++)
+                r.poly.p[j][k] = verts[f * 9 + j * 3 + k];
+        r.box = r.poly.box();
+        r.tri = f;
+        r.priority = split_priority(r);
+        scene.grow(r.box);
+    }
+    int64_t extra = static_cast<int64_t>(budget * n_tris);
+    if (extra <= 0 || n_tris < 16)
+        return;
+    // references whose box has less spare surface than a 4096th of the scene's are left alone
+    const double floor_priority = scene.area() / 4096.0 * 1e-3;
+    std::priority_queue<std::pair<double, int32_t>> open;
+    for (int f = 0; f < n_tris; f++)
+        if (refs[f].priority > floor_priority)
+            open.push({refs[f].priority, f});
+    while (extra > 0 && !open.empty())
+    {
+        const int32_t i = open.top().second;
+        open.pop();
+        // the most important grid plane over the three axes (lowest level; ties: the longest extent)
+        int best_axis = -1, best_level = 99;
+        double best_plane = 0, best_ext = -1;
+        for (int ax = 0; ax < 3; ax++)
+        {
+            double plane;
+            int level;
+            if (!grid_plane(scene.lo[ax], scene.hi[ax], refs[i].box.lo[ax], refs[i].box.hi[ax], plane, level))
+                continue;
+            const double ext = refs[i].box.hi[ax] - refs[i].box.lo[ax];
+            if (level < best_level || (level == best_level && ext > best_ext))
+                best_axis = ax, best_level = level, best_plane = plane, best_ext = ext;
+        }
+        if (best_axis < 0)
+            continue;
+        SplitRef lo_half, hi_half;
+        lo_half.poly = refs[i].poly.clip(best_axis, best_plane, true);
+        hi_half.poly = refs[i].poly.clip(best_axis, best_plane, false);
+        if (lo_half.poly.n < 3 || hi_half.poly.n < 3)
+            continue; // the plane only touches the polygon
+        lo_half.tri = hi_half.tri = refs[i].tri;
+        lo_half.box = lo_half.poly.box(), hi_half.box = hi_half.poly.box();
+        // a half's box never leaves the box it was cut from (rounding of the cut points aside)
+        for (int k = 0; k < 3; k++)
+        {
+            lo_half.box.lo[k] = std::max(lo_half.box.lo[k], refs[i].box.lo[k]), lo_half.box.hi[k] = std::min(lo_half.box.hi[k], refs[i].box.hi[k]);
+            hi_half.box.lo[k] = std::max(hi_half.box.lo[k], refs[i].box.lo[k]), hi_half.box.hi[k] = std::min(hi_half.box.hi[k], refs[i].box.hi[k]);
+        }
+        lo_half.priority = split_priority(lo_half), hi_half.priority = split_priority(hi_half);
+        // cutting must pay: the two boxes together clearly smaller than the one
+        if (!(lo_half.box.area() + hi_half.box.area() < 0.9 * refs[i].box.area()))
+            continue;
+        refs[i] = lo_half;
+        refs.push_back(hi_half);
+        extra--;
+        if (lo_half.priority > floor_priority)
+            open.push({lo_half.priority, i});
+        if (hi_half.priority > floor_priority)
+            open.push({hi_half.priority, static_cast<int32_t>(refs.size()) - 1});
+    }
+}
 
 
 // collapse of the binary tree into 4-wide nodes.  The binary tree ends in leaves of up to four
@@ -379,63 +551,62 @@ void hot_nodes_first(std::vector<BvhNode> &nodes, int hot)
 
 } // namespace
 
-void build_bvh(const float *verts, int n_tris, Bvh &out, bool median)
+void build_bvh(const float *verts, int n_tris, Bvh &out, bool median, double split_budget)
 {
     Builder B;
     B.verts = verts;
     B.max_leaf = 4;
     B.median = median;
-    B.tri_box.resize(n_tris);
-    B.centroid.resize(static_cast<size_t>(n_tris) * 3);
-    B.order.resize(n_tris);
+    std::vector<SplitRef> refs;
+    split_references(verts, std::max(n_tris, 0), median ? 0.0 : split_budget, refs);
+    const int n_refs = static_cast<int>(refs.size());
+    B.tri_box.resize(n_refs);
+    B.centroid.resize(static_cast<size_t>(n_refs) * 3);
+    B.ref_tri.resize(n_refs);
+    B.order.resize(n_refs);
     double max_abs = 0;
-    for (int f = 0; f < n_tris; f++)
+    for (int r = 0; r < n_refs; r++)
     {
-        B.order[f] = f;
-        double c[3] = {0, 0, 0};
-        for (int j = 0; j < 3; j++)
-        {
-            double p[3];
-            for (int k = 0; k < 3; k++)
-            {
-                p[k] = verts[f * 9 + j * 3 + k];
-                c[k] += p[k];
-                max_abs = std::max(max_abs, std::fabs(p[k]));
-            }
-            B.tri_box[f].grow(p);
-        }
+        B.order[r] = r;
+        B.tri_box[r] = refs[r].box;
+        B.ref_tri[r] = refs[r].tri;
         for (int k = 0; k < 3; k++)
-            B.centroid[f * 3 + k] = c[k] / 3.0;
+        {
+            B.centroid[static_cast<size_t>(r) * 3 + k] = 0.5 * (refs[r].box.lo[k] + refs[r].box.hi[k]);
+            max_abs = std::max(max_abs, std::max(std::fabs(refs[r].box.lo[k]), std::fabs(refs[r].box.hi[k])));
+        }
     }
     B.pad_abs = 1e-6 * (1.0 + max_abs);
 
     out = Bvh();
     out.median = median;
-    out.n_leaves = std::max(n_tris, 0);
+    out.n_leaves = n_refs;
     Collapser C{B};
     int need = 0;
-    if (n_tris <= 0)
+    if (n_refs <= 0)
     {
         C.out.emplace_back();
         C.emit(0, nullptr, nullptr, 0); // a root without children
     }
-    else if (n_tris <= 4)
+    else if (n_refs <= 4)
     {
         // no tree to speak of: one node whose children are the triangles
         Collapser::Slot all;
-        all.ref = ~static_cast<int32_t>(n_tris - 1);
+        all.ref = ~static_cast<int32_t>(n_refs - 1);
         C.leaf_node(all, 0, need);
     }
     else
     {
-        B.build(0, n_tris, 0); // more triangles than a leaf holds: the root is binary node 0
+        B.build(0, n_refs, 0); // more triangles than a leaf holds: the root is binary node 0
         Collapser::Slot top[4];
         Collapser::children(B.nodes[0], top[0], top[1]);
         C.collapse(top, 2, 0, need);
     }
     out.nodes = std::move(C.out);
     hot_nodes_first(out.nodes, HOT_NODES);
-    out.tri_order = std::move(B.order);
+    out.tri_order.resize(n_refs);
+    for (int k = 0; k < n_refs; k++)
+        out.tri_order[k] = B.ref_tri[B.order[k]];
     out.max_depth = C.max_depth;
     out.stack_need = need;
 }

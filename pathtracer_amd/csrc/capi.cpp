@@ -295,12 +295,16 @@ int ptx_scene_bvh_check(const ptx_scene *s, int32_t median, int64_t *info6)
     PTX_TRY
     const ptx::Scene &sc = s->sc;
     ptx::Bvh b;
-    ptx::build_bvh(sc.verts.data(), sc.n_tris(), b, median != 0);
-    const int F = sc.n_tris();
-    std::vector<int> seen(std::max(F, 1), 0);
+    // median: 0 = SAH, 1 = median splits, 2 = SAH with reference splitting (budget BVH_SPLIT_BUDGET)
+    ptx::build_bvh(sc.verts.data(), sc.n_tris(), b, median == 1, median == 2 ? ptx::BVH_SPLIT_BUDGET : 0.0);
+    const int F = sc.n_tris(), K = static_cast<int>(b.tri_order.size());
+    std::vector<int> seen(std::max(K, 1), 0);
+    // the boxes stored with the references of every face: [face] -> list of (lo, hi)
+    struct RefBox { float lo[3], hi[3]; };
+    std::vector<std::vector<RefBox>> boxes(std::max(F, 1));
     int64_t children = 0, violations = 0;
-    // walk the tree: every child box must lie inside its parent's box for that child, every
-    // triangle's vertices inside the box stored with it, and the stack bound must hold on every path
+    // walk the tree: every child box must lie inside its parent's box for that child and the stack
+    // bound must hold on every path
     struct Item { int32_t node; float lo[3], hi[3]; int depth_need; bool has_box; };
     std::vector<Item> todo;
     Item root{};
@@ -337,33 +341,62 @@ int ptx_scene_bvh_check(const ptx_scene *s, int32_t median, int64_t *info6)
             }
             else
             {
-                const int k_tri = ~ch;
-                if (k_tri < 0 || k_tri >= F)
+                const int k_ref = ~ch;
+                if (k_ref < 0 || k_ref >= K || b.tri_order[k_ref] < 0 || b.tri_order[k_ref] >= F)
                 {
                     violations++;
                     continue;
                 }
-                seen[k_tri]++;
-                const float *v = &sc.verts[static_cast<size_t>(b.tri_order[k_tri]) * 9];
-                for (int j = 0; j < 3; j++)
-                    for (int k = 0; k < 3; k++)
-                        if (!(v[j * 3 + k] > nd.lo[k][i] && v[j * 3 + k] < nd.hi[k][i]))
-                            violations++;
+                seen[k_ref]++;
+                RefBox rb;
+                for (int k = 0; k < 3; k++)
+                    rb.lo[k] = nd.lo[k][i], rb.hi[k] = nd.hi[k][i];
+                boxes[b.tri_order[k_ref]].push_back(rb);
             }
         }
     }
     int64_t refs = 0;
-    for (int k = 0; k < F; k++)
+    for (int k = 0; k < K; k++)
     {
         refs += seen[k];
         if (seen[k] != 1)
-            violations++;
+            violations++; // every reference hangs in the tree exactly once
     }
-    std::vector<int> perm(b.tri_order.begin(), b.tri_order.end());
-    std::sort(perm.begin(), perm.end());
-    for (int k = 0; k < F; k++)
-        if (perm[k] != k)
+    // every face is covered by the boxes of its references: its corners, and a grid of points over it,
+    // each lie strictly inside at least one of them (a face that was not cut has one box holding all of it)
+    for (int f = 0; f < F; f++)
+    {
+        const float *v = &sc.verts[static_cast<size_t>(f) * 9];
+        if (boxes[f].empty())
+        {
             violations++;
+            continue;
+        }
+        const int G = boxes[f].size() == 1 ? 1 : 12;
+        for (int i = 0; i <= G; i++)
+            for (int j = 0; i + j <= G; j++)
+            {
+                const double wa = double(i) / G, wb = double(j) / G, wc = 1.0 - wa - wb;
+                double p[3];
+                for (int k = 0; k < 3; k++)
+                    p[k] = wa * v[k] + wb * v[3 + k] + wc * v[6 + k];
+                bool inside = false;
+                for (const RefBox &rb : boxes[f])
+                {
+                    bool in = true;
+                    for (int k = 0; k < 3; k++)
+                        in = in && p[k] > rb.lo[k] && p[k] < rb.hi[k];
+                    inside = inside || in;
+                }
+                if (!inside)
+                    violations++;
+            }
+        if (G == 1)
+            for (int j = 0; j < 3; j++)
+                for (int k = 0; k < 3; k++)
+                    if (!(v[j * 3 + k] > boxes[f][0].lo[k] && v[j * 3 + k] < boxes[f][0].hi[k]))
+                        violations++;
+    }
     if (worst_need > b.stack_need)
         violations++;
     info6[0] = static_cast<int64_t>(b.nodes.size());
@@ -417,6 +450,8 @@ int ptx_context_set_option(ptx_context *c, const char *name, int64_t value)
         c->ctx->lds_stack_levels = static_cast<int>(value);
     else if (n == "lds_nodes" && value >= -1 && value <= (1 << 20))
         c->ctx->lds_nodes = static_cast<int>(value);
+    else if (n == "bvh_split" && value >= 0 && value <= 400)
+        c->ctx->bvh_split = static_cast<int>(value);
     else if (n == "bvh_rings" && (value == 0 || value == 1))
         c->ctx->bvh_rings = value != 0;
     else if (n == "ring_batch" && value >= 1 && value <= 64)

@@ -126,7 +126,9 @@ template <class R> struct Context::Impl
 
     void build_tables(const Scene &sc, const Bvh &bvh, bool brute, hipStream_t s)
     {
-        const int F = sc.n_tris();
+        // intersector order: the faces themselves (all-triangles intersector) or the references of the
+        // BVH's leaves (a face cut by reference splitting appears once per reference)
+        const int F = brute ? sc.n_tris() : static_cast<int>(bvh.tri_order.size());
         std::vector<R> pre(static_cast<size_t>(std::max(F, 1)) * 12, R(0));
         for (int k = 0; k < F; k++)
         {
@@ -479,14 +481,14 @@ void Context::build_accel(const Scene &sc)
     }
     static_assert(PLANE_REC_STRIDE == PQ_STRIDE, "record stride");
     bvh_ = Bvh();
-    build_bvh(sc.verts.data(), sc.n_tris(), bvh_);
+    build_bvh(sc.verts.data(), sc.n_tris(), bvh_, /*median=*/false, bvh_split / 100.0);
     if (!brute_ && bvh_.stack_need > BVH_STACK_MAX)
         build_bvh(sc.verts.data(), sc.n_tris(), bvh_, /*median=*/true); // balanced tree: depth ~ log4 n
     if (!brute_ && bvh_.stack_need > BVH_STACK_MAX)
         throw std::runtime_error("state: BVH deeper than the traversal stack");
     {
         // a stack entry keeps the record id in its low bits and the entry distance in the rest
-        const uint64_t n_rec = bvh_.nodes.size() + static_cast<uint64_t>(std::max(sc.n_tris(), 0));
+        const uint64_t n_rec = bvh_.nodes.size() + static_cast<uint64_t>(bvh_.tri_order.size());
         id_bits_ = 1;
         while ((uint64_t(1) << id_bits_) < n_rec)
             id_bits_++;
@@ -499,12 +501,14 @@ void Context::build_accel(const Scene &sc)
         throw std::runtime_error("arg: Depth above 65535 is not supported");
     delete geo_;
     geo_ = new Geometry();
-    std::vector<int32_t> face(std::max(sc.n_tris(), 1), 0);
-    for (int k = 0; k < sc.n_tris(); k++)
+    // intersector order: faces (all-triangles intersector) or the triangle references of the BVH's leaves
+    const int n_entries = brute_ ? sc.n_tris() : static_cast<int>(bvh_.tri_order.size());
+    std::vector<int32_t> face(std::max(n_entries, 1), 0);
+    for (int k = 0; k < n_entries; k++)
         face[k] = brute_ ? k : bvh_.tri_order[k];
     upload(geo_->tri_face, face, s);
-    std::vector<int32_t> tmat(std::max(sc.n_tris(), 1), -1);
-    for (int k = 0; k < sc.n_tris(); k++)
+    std::vector<int32_t> tmat(std::max(n_entries, 1), -1);
+    for (int k = 0; k < n_entries; k++)
         tmat[k] = sc.mat_ids[face[k]];
     upload(geo_->tri_mat, tmat, s);
     upload(geo_->verts, sc.verts, s);

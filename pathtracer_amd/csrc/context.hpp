@@ -100,6 +100,7 @@ public:
     // BVH tracer: at most this many node records (the first ones: the builder numbers the busiest
     // nodes first) in LDS behind the stack levels (-1: what fits next to 16 stack levels; 0: none)
     int lds_nodes = -1;
+    int bvh_split = 0; // reference splitting: at most this many extra triangle references per 100 triangles (0: none, the default: fewer triangle tests, more node visits, no net gain measured)
     // BVH scenes with at most 12 square lights: the tracer that queues hits and rays per wave (ring tracer)
     // instead of the one that keeps every path on its lane
     bool bvh_rings = true;

@@ -1,6 +1,7 @@
 """CPU tests of the host-built 4-wide BVH (ptx_scene_bvh_check): every triangle referenced exactly
 once, child boxes nested, triangles strictly inside their boxes, and the stack bound reported by the
-builder holds on every root-to-leaf path -- for the SAH tree and for the median-split fallback."""
+builder holds on every root-to-leaf path -- for the SAH tree and for the median-split fallback; with
+reference splitting a triangle hangs in the tree through several references whose boxes cover it."""
 import os
 
 import pytest
@@ -53,3 +54,18 @@ def test_tiny_and_degenerate_scenes(root):
     for median in (False, True):
         info = scene_of(verts).bvh_check(median=median)
         assert info["violations"] == 0 and info["triangle_refs"] == 37
+
+
+@pytest.mark.parametrize("conf", ["config/cbox.conf", "config/mis.conf", "config/room.conf"])
+def test_reference_splitting_keeps_the_invariants(root, conf):
+    """Reference splitting (off by default, option bvh_split): more references than triangles, every
+    reference in the tree once, every triangle covered by the boxes of its references (a grid of points
+    over it, each strictly inside one of them), child boxes nested, stack bound kept."""
+    s = pt.Scene.load_conf(os.path.join(root, conf), root_dir=root, width=8, height=8, spp=1)
+    plain, cut = s.bvh_check(), s.bvh_check(split=True)
+    n = s.info.n_tris
+    assert cut["violations"] == 0
+    assert n < cut["triangle_refs"] <= n + int(0.3 * n) + 1 or n < 16
+    assert cut["n_children"] == cut["triangle_refs"] + cut["n_nodes"] - 1
+    assert cut["stack_need"] <= 96
+    assert plain["triangle_refs"] == n

@@ -319,6 +319,33 @@ def test_bvh_stack_spill_is_bit_invariant(root, conf, kw):
         assert np.array_equal(base, imgs[("f64",)][0])
 
 
+@pytest.mark.parametrize("conf,kw", [("config/mis.conf", dict(width=96, height=64, spp=4)),
+                                     ("config/room.conf", dict(width=96, height=64, spp=2)),
+                                     ("config/cbox.conf", dict(width=64, height=64, spp=4))])
+def test_reference_splitting_is_bit_invariant(root, conf, kw):
+    """Option bvh_split: triangles with mostly empty boxes hang in the tree through several references
+    (each with the box of its part).  The intersector tests the whole triangle wherever it meets it, so
+    first hits, hit points and images are those of the unsplit tree to the bit, in both precisions and
+    under both estimators; only the visit counts move (fewer triangle tests)."""
+    s, ref = load(root, conf, **kw)
+    out = {}
+    for split in (0, 30, 200):
+        c = pt.Context(0, brute_force_limit=0)
+        c.set_option("bvh_split", split)
+        c.build_accel(s)
+        assert (c.accel_info()["n_leaves"] > ref.verts.shape[0]) == (split > 0)
+        ids, pts = c.first_hit(with_points=True)
+        got = [ids, pts]
+        for mode, est in (("f64", "reference"), ("f32", "reference"), ("f64", "fast")):
+            img, st = c.render(mode=mode, estimator=est)
+            got += [img, np.array([st["segments"], st["shadow_rays"], st["records"]])]
+        if split == 0:
+            out = got
+        else:
+            for a, b in zip(out, got):
+                assert np.array_equal(a, b, equal_nan=True), split
+
+
 @pytest.mark.parametrize("conf,kw", [("config/mis.conf", dict(width=160, height=96, spp=8)),
                                      ("config/room.conf", dict(width=96, height=64, spp=3)),
                                      ("config/cbox.conf", dict(width=96, height=96, spp=6))])
