@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--estimator", default="reference", choices=["reference", "fast"],
                     help="the estimator of the timed steps: the reference's own (the metric) or the physically based one "
                          "(profiling sessions of its kernels; the line then says so in config.estimator)")
+    ap.add_argument("--no-scenes", action="store_true", help="skip the one timed step each of config/room.conf and config/mis.conf")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--scheme", default="samples", choices=["samples", "bands"],
                     help="multi-GPU sharding: 'samples' = every rank renders --spp samples of every pixel (weak "
@@ -208,11 +209,12 @@ def main():
         def render_fn(o, **kw):
             return ctx.render_device(o.data_ptr(), **kw)
 
-    def step(profile=False, mode=None, reduce=True):
+    def step(profile=False, mode=None, reduce=True, scheme=None, reduce_ms=None):
         # samples: rank r renders samples [r*spp, (r+1)*spp) of every pixel; bands: its rows of the
         # frame (the rest of `out` stays zero); then RCCL reduce(sum) -> rank 0
-        return render_frame(render_fn, out, spp_total, rank, world, scheme=args.scheme, reduce=reduce and use_dist,
-                            collective=use_dist,
+        scheme = scheme or args.scheme
+        return render_frame(render_fn, out, args.spp * world if scheme == "samples" else args.spp, rank, world, scheme=scheme,
+                            reduce=reduce and use_dist, collective=use_dist, reduce_ms=reduce_ms,
                             mode=mode or args.mode, seed=13, profile=profile,
                             **({"estimator": "fast"} if args.estimator == "fast" else {}))
 
@@ -222,20 +224,54 @@ def main():
         if not rehearsal:
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=out.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(scheme, steps, warmup):
+        """warmup untimed steps, then `steps` steps between two fences; the MAX over the ranks"""
+        for _ in range(warmup):
+            step(scheme=scheme)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st_ = step(scheme=scheme)
+        fence()
+        dt_ = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt_], dtype=torch.float64, device=out.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_, st_
+
+    dt, st = timed(args.scheme, args.steps, args.warmup)
     paths_per_step = W * H * spp_total
     value = paths_per_step * args.steps / dt / 1e6
+    frame_checksum = float(out.double().sum().item()) if rehearsal and rank == 0 else None   # of the frame the timed steps made
+
+    # N > 1: the other way of cutting the frame too, in the same line, so that a scaling record cannot
+    # be misread: "weak" = every rank renders --spp samples of every pixel (N x the work), "strong" =
+    # the ranks share the rows of ONE --spp frame; each with the duration of its exchange
+    both = None
+    if world > 1:
+        other = "bands" if args.scheme == "samples" else "samples"
+        dt_o, _ = timed(other, args.steps, 1)
+        rms = {}
+        for sch in ("samples", "bands"):
+            acc = []
+            step(scheme=sch, reduce_ms=acc)
+            fence()
+            rms[sch] = acc[0] if acc else None
+        if use_dist:
+            for sch in rms:
+                t = torch.tensor([rms[sch] or 0.0], dtype=torch.float64, device=out.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                rms[sch] = float(t.item())
+        dts = {args.scheme: dt, other: dt_o}
+        both = {
+            "weak": {"scheme": "samples", "value": round(W * H * args.spp * world * args.steps / dts["samples"] / 1e6, 6), "unit": "Mpaths/s",
+                     "ms_per_step": round(dts["samples"] / args.steps * 1e3, 3), "global_spp": args.spp * world,
+                     "reduce_ms": None if rms["samples"] is None else round(rms["samples"], 3)},
+            "strong": {"scheme": "bands", "value": round(W * H * args.spp * args.steps / dts["bands"] / 1e6, 6), "unit": "Mpaths/s",
+                       "ms_per_step": round(dts["bands"] / args.steps * 1e3, 3), "global_spp": args.spp,
+                       "reduce_ms": None if rms["bands"] is None else round(rms["bands"], 3)},
+            "exchange": "reduce(sum) of the whole f64 frame onto rank 0 (%d bytes per rank)" % (W * H * 24)}
 
     result = None
     if rank == 0 and rehearsal:
@@ -246,7 +282,8 @@ def main():
                   "data": "rehearsal on the CPU over gloo (%s): no measurement" % args.rehearse,
                   "config": {"workload": "%s %dx%d, %d spp per rank" % (scene_name, W, H, args.spp), "global_spp": spp_total,
                              "paths_per_step": paths_per_step},
-                  "frame_checksum": float(out.double().sum().item()), "roofline": None, "cpu_baseline": None}
+                  "weak": both and both["weak"], "strong": both and both["strong"],
+                  "frame_checksum": frame_checksum, "roofline": None, "cpu_baseline": None}
     elif rank == 0:
         # ---- roofline of the dominant kernel: one more step with HIP events around every launch
         # on the render stream (same workload, same stream; not part of the timed region above)
@@ -343,6 +380,17 @@ def main():
         if not args.no_cpu_baseline and world == 1 and args.estimator == "reference":
             cpu, checks = cpu_baseline_and_checks(ctx, args, W, H)
 
+        # the two BVH scenes of the configuration list, one timed step each at their own sizes, after the
+        # timed region of the metric and outside it (headline run on one GPU only)
+        scenes = None
+        if headline and world == 1 and not args.no_scenes:
+            scenes = {}
+            for name, sw, sh, sspp in (("room", 1024, 1024, 64), ("mis", 768, 512, 256)):
+                try:
+                    scenes[name] = time_scene(name, sw, sh, sspp, args, local_rank, stream, check=not args.no_cpu_baseline)
+                except Exception as e:  # a missing scene file must not cost the metric its line
+                    scenes[name] = {"error": str(e)[:200]}
+
         result = {
             "metric": "Mpaths/s at %s %dx%d (whole job, all GPUs)" % (scene_name, W, H), "value": round(value, 3), "unit": "Mpaths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -365,12 +413,51 @@ def main():
             "other_mode": {"dtype": other_mode, "value": None if other_value is None else round(other_value, 3),
                            "wave_iterations": int(ost["wave_iterations"]), "passes": int(ost["passes"])},
             "fast_estimator": fast, "cpu_baseline": cpu, "checks": checks,
+            "weak": both and both["weak"], "strong": both and both["strong"], "scenes": scenes,
         }
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def time_scene(name, W, H, spp, args, device, stream, check=True):
+    """One timed step of another scene of the configuration list (f64 and f32, the reference's
+    estimator): Mpaths/s over the whole step with the frame resident on the device, and -- with the CPU
+    oracle at hand -- the first-hit face ids of all its camera rays against the oracle's."""
+    import torch
+
+    import pathtracer_amd as pt
+    conf = "config/%s.conf" % name
+    scene = pt.Scene.load_conf(os.path.join(ROOT, conf), root_dir=ROOT, width=W, height=H, spp=spp)
+    ctx = pt.Context(device, stream=stream.cuda_stream)
+    ctx.build_accel(scene)
+    out = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+    rec = {"workload": "%s %dx%d, %d spp, depth %d, %d triangles, %d lights (%s)" % (
+        name, W, H, spp, scene.info.depth, scene.info.n_tris, scene.info.n_lights, conf)}
+    for mode in (args.mode, "f32" if args.mode == "f64" else "f64"):
+        ctx.render_device(out.data_ptr(), mode=mode, spp=1, seed=13)          # kernels and state, untimed
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st = ctx.render_device(out.data_ptr(), mode=mode, spp=spp, seed=13)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        key = "value" if mode == args.mode else "value_" + mode
+        rec[key] = round(W * H * spp / dt / 1e6, 3)
+        if mode == args.mode:
+            rec.update({"unit": "Mpaths/s", "dtype": mode, "ms_per_step": round(dt * 1e3, 3), "tracer_kernel": ctx.last_kernel(),
+                        "segments_per_path": round(st["segments"] / st["paths"], 3),
+                        "mrays_per_s": round((st["segments"] + st["shadow_rays"]) / dt / 1e6, 1),
+                        "bvh_nodes_per_ray": round(st["bvh_nodes"] / max(st["segments"] + st["shadow_rays"], 1), 2),
+                        "bvh_tris_per_ray": round(st["bvh_tris"] / max(st["segments"] + st["shadow_rays"], 1), 2)})
+    if check:
+        from oracle import oracle, scene_io
+        ref = scene_io.load_conf(os.path.join(ROOT, conf), root_dir=ROOT, width=W, height=H, spp=1)
+        oids = oracle.Oracle(ref, seed=13).first_hit()
+        ids = ctx.first_hit()
+        rec.update({"first_hit_mismatches": int((ids != oids).sum()), "first_hit_pixels": int(ids.size)})
+    return rec
 
 
 def cpu_baseline_and_checks(ctx, args, W, H):

@@ -24,11 +24,13 @@ def shard_bands(rank, world, band=8):
 
 
 def render_frame(render_fn, out, spp_total, rank=0, world=1, scheme="samples", band=8, reduce=True,
-                 collective=None, **kw):
+                 collective=None, reduce_ms=None, **kw):
     """Renders this rank's share into `out` (a torch tensor [H,W,3] float64 on the rank's device)
     and reduces onto rank 0.  `render_fn(out, **options)` fills `out` with pre-clamp sums; for the
     GPU core it is `lambda out, **o: ctx.render_device(out.data_ptr(), **o)`.  `collective`: run
-    the reduce even in a world of one (default: only when world > 1)."""
+    the reduce even in a world of one (default: only when world > 1).  reduce_ms: a list that
+    receives the duration of the exchange in milliseconds (events on the tensor's stream; host clock
+    for CPU tensors): the one step of a frame that is not rendering."""
     if scheme == "samples":
         offset, count = shard_samples(spp_total, rank, world)
         if count > 0:
@@ -42,5 +44,19 @@ def render_frame(render_fn, out, spp_total, rank=0, world=1, scheme="samples", b
         raise ValueError("scheme must be 'samples' or 'bands'")
     if reduce and (world > 1 if collective is None else collective):
         import torch.distributed as dist
-        dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+        if reduce_ms is None:
+            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+        elif out.is_cuda:
+            import torch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+            e1.record()
+            e1.synchronize()
+            reduce_ms.append(e0.elapsed_time(e1))
+        else:
+            import time
+            t0 = time.perf_counter()
+            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+            reduce_ms.append((time.perf_counter() - t0) * 1e3)
     return stats

@@ -94,6 +94,12 @@ def test_bench_starts_its_own_ranks(scheme):
     sc = scene_io.load_conf(os.path.join(ROOT, "config/cbox.conf"), root_dir=ROOT, width=24, height=24, spp=total)
     full = oracle.Oracle(sc, seed=13).render(threads=1)
     assert abs(res["frame_checksum"] - float(full.sum())) <= 1e-10
+    # both cuts of the frame are in the one line, whichever the headline value is: weak = 3 spp per rank,
+    # strong = the two ranks share one 3-spp frame; each with the duration of its exchange
+    assert res["weak"]["global_spp"] == 6 and res["strong"]["global_spp"] == 3
+    assert res["weak"]["value"] > 0 and res["strong"]["value"] > 0
+    assert res["weak"]["reduce_ms"] >= 0 and res["strong"]["reduce_ms"] >= 0
+    assert abs(res[("weak" if scheme == "samples" else "strong")]["value"] / res["value"] - 1) < 1e-3
 
 
 def test_bench_reports_failing_ranks():
