@@ -6,7 +6,8 @@ closest hit / shading / NEE with visibility per path, resolve, accumulate -- i.e
 cPathTracer::Process of the reference for
 config/cbox.conf at 1024 x 1024 x 256 spp (the configuration the headline metric is quoted on).  With N GPUs every rank
 renders its own range of 256 samples of the same image (weak scaling: 256 * N spp in total) and the
-per-pixel sums are reduced onto rank 0 over RCCL inside the timed region.
+per-pixel sums are reduced onto rank 0 over RCCL inside the timed region (--scheme bands: the ranks
+share the rows of one frame and rank 0 gathers each rank's packed rows).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode f64|f32] [--spp S] [--size W]
 
@@ -271,7 +272,10 @@ def main():
             "strong": {"scheme": "bands", "value": round(W * H * args.spp * args.steps / dts["bands"] / 1e6, 6), "unit": "Mpaths/s",
                        "ms_per_step": round(dts["bands"] / args.steps * 1e3, 3), "global_spp": args.spp,
                        "reduce_ms": None if rms["bands"] is None else round(rms["bands"], 3)},
-            "exchange": "reduce(sum) of the whole f64 frame onto rank 0 (%d bytes per rank)" % (W * H * 24)}
+            "exchange": "weak: reduce(sum) of the whole f64 frame onto rank 0 (%d bytes per rank); strong: gather of every rank's "
+                        "own rows, packed (%d bytes per rank)" % (W * H * 24, W * H * 24 // world)}
+        both["weak"]["exchange_bytes_per_rank"] = W * H * 24
+        both["strong"]["exchange_bytes_per_rank"] = W * H * 24 // world
 
     result = None
     if rank == 0 and rehearsal:
@@ -403,8 +407,8 @@ def main():
                        "intersector": "all-triangles (plane records)" if ctx.accel_info()["brute_force"] else "BVH",
                        "tracer_kernel": ran, "state_bytes": int(ps["state_bytes"]), "estimator": args.estimator,
                        "global_spp": spp_total, "paths_per_step": paths_per_step,
-                       "sharding": ("sample ranges per rank" if args.scheme == "samples" else "interleaved row bands of 8 per rank")
-                                   + " + RCCL reduce(sum) of the radiance sums to rank 0"},
+                       "sharding": ("sample ranges per rank + RCCL reduce(sum) of the radiance sums to rank 0" if args.scheme == "samples"
+                                    else "interleaved row bands of 8 per rank + RCCL gather of each rank's packed rows to rank 0")},
             "mrays_per_s": round((st["segments"] + st["shadow_rays"]) * world * args.steps / dt / 1e6, 1),
             "segments_per_path": round(st["segments"] / st["paths"], 3),
             "roofline": roofline, "valu": valu, "kernels": kernels, "kernel_ms_per_step": kernel_ms,

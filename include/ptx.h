@@ -71,8 +71,17 @@ typedef struct ptx_scene_info
     double fov_deg, near_plane, world_scale;
 } ptx_scene_info;
 
+/* ABI version of this header.  Version 2 put struct_size in front of ptx_render_opts and ptx_stats:
+ * the caller writes sizeof(the struct it was compiled against) there, the library reads / writes
+ * that many bytes and treats fields beyond them as zero, so that fields can be appended without
+ * breaking callers built against an older header.  A struct_size of 0 is refused (PTX_ERR_ARG): it
+ * marks a caller built against version 1, whose structs had no such field.  ptx_abi_version() returns
+ * the version the loaded library was built with. */
+#define PTX_ABI_VERSION 2
+
 typedef struct ptx_render_opts
 {
+    uint32_t struct_size;  /* sizeof(ptx_render_opts) as the caller knows it                     */
     int32_t mode;          /* PTX_MODE_F64 | PTX_MODE_F32                                        */
     int32_t spp;           /* samples rendered by this call (<=0: scene spp)                     */
     int32_t sample_offset; /* global index of the first sample (sample-range sharding)           */
@@ -86,10 +95,19 @@ typedef struct ptx_render_opts
     int32_t accumulate;    /* != 0: add to the sums already in the output buffer                 */
     int32_t profile;       /* != 0: time every kernel with HIP events (fills ms_*)                 */
     int32_t estimator;     /* PTX_ESTIMATOR_REFERENCE | PTX_ESTIMATOR_FAST                         */
+    int32_t enqueue_only;  /* != 0: the call puts its work on the context's stream and returns without
+                              waiting for it or reading anything back: no statistics (only passes and
+                              state_bytes are filled), no timing, every bounce the depth allows is
+                              launched (deep scenes otherwise stop early once a queue count read back
+                              from the device says no ray is left).  Device output only.  With
+                              ptx_render_static the call then contains nothing a stream capture
+                              (hipStreamBeginCapture .. hipStreamEndCapture) refuses.               */
 } ptx_render_opts;
 
 typedef struct ptx_stats
 {
+    uint32_t struct_size;   /* sizeof(ptx_stats) as the caller knows it, set BEFORE the call     */
+    uint32_t reserved_;
     uint64_t paths;         /* pixel-samples traced                                              */
     uint64_t segments;      /* closest-hit rays (one per bounce of every path)                   */
     uint64_t shadow_rays;   /* visibility tests issued                                           */
@@ -213,8 +231,10 @@ int ptx_vistest(ptx_context *, const double *p1, const double *p2, int64_t n, in
  * counter profiles to the kernel that actually ran. */
 const char *ptx_context_last_kernel(const ptx_context *);
 
-/* ptx_render_static: ptx_render for callers that cannot allocate -- code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.
+/* ptx_render_static: ptx_render for callers that cannot allocate -- tight serving loops, harnesses
+ * that forbid hipMalloc, code under HIP stream capture (there with opts->enqueue_only set: without
+ * it the call waits for its stream to read the statistics back, which a capture refuses).  It has
+ * no counterpart in the reference.
  * Same kernels, same results as ptx_render with out_is_device != 0 (rgb_sum is DEVICE memory,
  * [H*W][3] double, on the context's GPU), but the path state (record slots, per-path results,
  * statistics, rings, stack spill) lives in a region of 256 MiB that the library holds in every
@@ -241,7 +261,11 @@ int ptx_render_static(ptx_context *, const ptx_render_opts *, double *rgb_sum_de
  *            contexts may share a GPU).
  * rgb_sum: HOST buffer [H*W][3], the same pre-clamp sums as ptx_render writes (bands: bit for bit
  * those of a single ptx_render; sample ranges: up to the order of the additions).  stats: n
- * entries, one per context, or NULL.  opts->row_stride/row_phase/accumulate are ignored. */
+ * entries, one per context (each with its struct_size set; the stride is that of the first), or
+ * NULL.  opts->row_stride/row_phase/accumulate are ignored.  Bands travel packed: only a context's
+ * own rows, W * H * 24 / n bytes per context (ncclSend / ncclRecv in one group, or one peer copy
+ * each); sample ranges reduce whole frames.  The contexts keep their frame buffers and host threads
+ * from call to call: a frame loop allocates on its first frame only. */
 #define PTX_SHARD_SAMPLES 0
 #define PTX_SHARD_BANDS 1
 #define PTX_EXCHANGE_RCCL 0
@@ -258,6 +282,9 @@ int ptx_write_ppm(const char *path, const double *rgb, int32_t width, int32_t he
 
 const char *ptx_last_error(void);
 const char *ptx_version(void);
+/* PTX_ABI_VERSION of the loaded library (no counterpart in the reference; callers compare it with
+ * the header they were built against before they pass structs). */
+int32_t ptx_abi_version(void);
 
 #ifdef __cplusplus
 }

@@ -32,18 +32,30 @@ class SceneInfo(C.Structure):
                 ("fov_deg", C.c_double), ("near_plane", C.c_double), ("world_scale", C.c_double)]
 
 
+PTX_ABI_VERSION = 2
+
+
 class RenderOpts(C.Structure):
-    _fields_ = [("mode", C.c_int32), ("spp", C.c_int32), ("sample_offset", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("mode", C.c_int32), ("spp", C.c_int32), ("sample_offset", C.c_int32),
                 ("spp_total", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32),
                 ("row_stride", C.c_int32), ("row_phase", C.c_int32), ("band", C.c_int32),
                 ("depth", C.c_int32), ("seed", C.c_uint64), ("batch_paths", C.c_int64),
-                ("accumulate", C.c_int32), ("profile", C.c_int32), ("estimator", C.c_int32)]
+                ("accumulate", C.c_int32), ("profile", C.c_int32), ("estimator", C.c_int32),
+                ("enqueue_only", C.c_int32)]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(RenderOpts)
 
 
 class Stats(C.Structure):
-    _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("shadow_rays", C.c_uint64),
+    _fields_ = [("struct_size", C.c_uint32), ("reserved_", C.c_uint32), ("paths", C.c_uint64), ("segments", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("passes", C.c_uint64), ("wave_iterations", C.c_uint64), ("records", C.c_uint64), ("bvh_nodes", C.c_uint64), ("bvh_tris", C.c_uint64), ("ms_total", C.c_double), ("ms_trace", C.c_double),
                 ("ms_accumulate", C.c_double), ("ms_other", C.c_double), ("state_bytes", C.c_uint64)]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(Stats)
 
 
 # every symbol include/ptx.h declares: name -> (restype, argtypes)
@@ -80,6 +92,7 @@ SYMBOLS = {
     "ptx_write_ppm": (C.c_int, [C.c_char_p, _VP, C.c_int32, C.c_int32]),
     "ptx_last_error": (C.c_char_p, []),
     "ptx_version": (C.c_char_p, []),
+    "ptx_abi_version": (C.c_int32, []),
 }
 
 _lib = None
@@ -104,6 +117,9 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        if L.ptx_abi_version() != PTX_ABI_VERSION:
+            raise RuntimeError("libptx_amd.so speaks ABI version %d, this binding %d: rebuild the library"
+                               % (L.ptx_abi_version(), PTX_ABI_VERSION))
         _lib = L
     return _lib
 

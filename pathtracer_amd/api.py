@@ -198,8 +198,9 @@ class Context:
         return vis.astype(bool)
 
     def _opts(self, mode, spp, sample_offset, spp_total, rows, row_stride, row_phase, band, depth,
-              seed, batch_paths, accumulate, profile, estimator="reference"):
+              seed, batch_paths, accumulate, profile, estimator="reference", enqueue_only=False):
         o = _lib.RenderOpts()
+        o.enqueue_only = int(bool(enqueue_only))
         o.mode = _MODES[mode]
         o.spp, o.sample_offset, o.spp_total = int(spp or 0), int(sample_offset), int(spp_total or 0)
         if rows is not None:
@@ -240,11 +241,12 @@ class Context:
 
     def render_static(self, device_ptr, mode="f64", spp=None, sample_offset=0, spp_total=None,
                       rows=None, row_stride=1, row_phase=0, band=1, depth=None, seed=13,
-                      batch_paths=None, accumulate=False, estimator="reference"):
+                      batch_paths=None, accumulate=False, estimator="reference", enqueue_only=False):
         """render_device through ptx_render_static: the path state lives in the library's static
-        device region and the call allocates nothing."""
+        device region and the call allocates nothing.  enqueue_only: it does not wait for the stream
+        or read anything back either (no statistics) -- what a stream capture needs."""
         o = self._opts(mode, spp, sample_offset, spp_total, rows, row_stride, row_phase, band,
-                       depth, seed, batch_paths, accumulate, False, estimator)
+                       depth, seed, batch_paths, accumulate, False, estimator, enqueue_only)
         st = _lib.Stats()
         check(_lib.lib().ptx_render_static(self._h, C.byref(o), C.c_void_p(int(device_ptr)), C.byref(st)))
         return _stats_dict(st)
@@ -267,6 +269,7 @@ def render_sharded(contexts, scheme="bands", exchange="rccl", mode="f64", spp=No
     o = ctxs[0]._opts(mode, spp, 0, spp_total, rows, 1, 0, band, depth, seed, batch_paths, False, False)
     out = np.zeros((ctxs[0].height, ctxs[0].width, 3))
     st = (_lib.Stats * len(ctxs))()
+    st[0].struct_size = C.sizeof(_lib.Stats)      # an array is made without running the elements' constructor
     check(_lib.lib().ptx_render_sharded(arr, len(ctxs), C.byref(o), {"samples": 0, "bands": 1}[scheme],
                                         {"rccl": 0, "peer": 1}[exchange], _ptr(out), st))
     return out, [_stats_dict(x) for x in st]

@@ -293,7 +293,7 @@ bool grid_plane(double lo, double hi, double a, double b, double &plane, int &le
 {
     if (!(hi > lo) || !(b > a))
         return false;
-    const double ua = (a - lo) / (hi - lo), ub = (b - lo) / (hi - lo);
+    const double ua = (a - lo) / (hi - lo);
     for (level = 1; level <= 40; level++)
     {
         const double cells = std::ldexp(1.0, level);

@@ -543,36 +543,54 @@ int ptx_vistest(ptx_context *c, const double *p1, const double *p2, int64_t n, i
     PTX_CATCH
 }
 
+// The caller's struct may be shorter (built against an older header) or longer (a newer one) than
+// this library's: struct_size bytes are the caller's, fields beyond them read as zero.
 static ptx::RenderOpts to_opts(const ptx_render_opts *o)
 {
     ptx::RenderOpts ro;
     if (o)
     {
-        ro.mode = o->mode;
-        ro.spp = o->spp, ro.sample_offset = o->sample_offset, ro.spp_total = o->spp_total;
-        ro.row_begin = o->row_begin, ro.row_end = o->row_end;
-        ro.row_stride = o->row_stride, ro.row_phase = o->row_phase, ro.band = o->band;
-        ro.depth = o->depth;
-        ro.seed = o->seed;
-        ro.batch_paths = o->batch_paths;
-        ro.accumulate = o->accumulate != 0;
-        ro.profile = o->profile != 0;
-        ro.estimator = o->estimator;
+        if (o->struct_size < sizeof(uint32_t) + sizeof(int32_t))
+            throw std::runtime_error("arg: ptx_render_opts.struct_size is not set (ABI version 2: write sizeof(ptx_render_opts) there)");
+        ptx_render_opts in;
+        std::memset(&in, 0, sizeof(in));
+        std::memcpy(&in, o, std::min<size_t>(o->struct_size, sizeof(in)));
+        ro.mode = in.mode;
+        ro.spp = in.spp, ro.sample_offset = in.sample_offset, ro.spp_total = in.spp_total;
+        ro.row_begin = in.row_begin, ro.row_end = in.row_end;
+        ro.row_stride = in.row_stride, ro.row_phase = in.row_phase, ro.band = in.band;
+        ro.depth = in.depth;
+        ro.seed = in.seed;
+        ro.batch_paths = in.batch_paths;
+        ro.accumulate = in.accumulate != 0;
+        ro.profile = in.profile != 0;
+        ro.estimator = in.estimator;
+        ro.enqueue_only = in.enqueue_only != 0;
     }
     return ro;
 }
 
+static void check_stats_arg(const ptx_stats *stats)
+{
+    if (stats && stats->struct_size < 2 * sizeof(uint32_t))
+        throw std::runtime_error("arg: ptx_stats.struct_size is not set (ABI version 2: write sizeof(ptx_stats) there before the call)");
+}
+
 static void from_stats(const ptx::RenderStats &st, ptx_stats *stats)
 {
-    stats->paths = st.paths, stats->segments = st.segments, stats->shadow_rays = st.shadow_rays;
-    stats->passes = st.passes;
-    stats->wave_iterations = st.wave_iterations;
-    stats->records = st.records;
-    stats->bvh_nodes = st.bvh_nodes, stats->bvh_tris = st.bvh_tris;
-    stats->ms_total = st.ms_total;
-    stats->ms_trace = st.ms_class[0], stats->ms_accumulate = st.ms_class[2];
-    stats->ms_other = st.ms_class[3];
-    stats->state_bytes = st.state_bytes;
+    ptx_stats out;
+    std::memset(&out, 0, sizeof(out));
+    out.struct_size = stats->struct_size;
+    out.paths = st.paths, out.segments = st.segments, out.shadow_rays = st.shadow_rays;
+    out.passes = st.passes;
+    out.wave_iterations = st.wave_iterations;
+    out.records = st.records;
+    out.bvh_nodes = st.bvh_nodes, out.bvh_tris = st.bvh_tris;
+    out.ms_total = st.ms_total;
+    out.ms_trace = st.ms_class[0], out.ms_accumulate = st.ms_class[2];
+    out.ms_other = st.ms_class[3];
+    out.state_bytes = st.state_bytes;
+    std::memcpy(stats, &out, std::min<size_t>(stats->struct_size, sizeof(out)));
 }
 
 int ptx_render(ptx_context *c, const ptx_render_opts *o, double *rgb_sum, int32_t out_is_device, ptx_stats *stats)
@@ -580,6 +598,7 @@ int ptx_render(ptx_context *c, const ptx_render_opts *o, double *rgb_sum, int32_
     if (!c || !c->ctx || !rgb_sum)
         return fail_arg("ptx_render: null argument");
     PTX_TRY
+    check_stats_arg(stats);
     ptx::RenderStats st;
     c->ctx->render(to_opts(o), rgb_sum, out_is_device != 0, st);
     if (stats)
@@ -592,12 +611,15 @@ int ptx_render_static(ptx_context *c, const ptx_render_opts *o, double *rgb_sum_
     if (!c || !c->ctx || !rgb_sum_device)
         return fail_arg("ptx_render_static: null argument");
     PTX_TRY
+    check_stats_arg(stats);
     ptx::RenderStats st;
     c->ctx->render(to_opts(o), rgb_sum_device, true, st, /*static_state=*/true);
     if (stats)
         from_stats(st, stats);
     PTX_CATCH
 }
+
+int32_t ptx_abi_version(void) { return PTX_ABI_VERSION; }
 
 const char *ptx_context_last_kernel(const ptx_context *c) { return (c && c->ctx) ? c->ctx->last_kernel().c_str() : ""; }
 
@@ -616,11 +638,20 @@ int ptx_render_sharded(ptx_context *const *contexts, int32_t n, const ptx_render
             throw std::runtime_error("arg: ptx_render_sharded: null context");
         cs[i] = contexts[i]->ctx;
     }
+    check_stats_arg(stats);
     std::vector<ptx::RenderStats> st(n);
     ptx::render_sharded(cs.data(), n, to_opts(o), scheme, exchange, rgb_sum, st.data());
     if (stats)
+    {
+        // the caller's array has the stride of the caller's struct
+        const size_t stride = stats->struct_size;
         for (int i = 0; i < n; i++)
-            from_stats(st[i], &stats[i]);
+        {
+            ptx_stats *dst = reinterpret_cast<ptx_stats *>(reinterpret_cast<char *>(stats) + static_cast<size_t>(i) * stride);
+            dst->struct_size = static_cast<uint32_t>(stride);
+            from_stats(st[i], dst);
+        }
+    }
     PTX_CATCH
 }
 

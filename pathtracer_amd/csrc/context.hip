@@ -15,6 +15,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 
@@ -66,11 +68,32 @@ template <class T> void upload(DeviceBuffer &b, const std::vector<T> &v, hipStre
 
 constexpr int MAX_TRACE_WAVES = 1 << 16; // rows of the per-wave statistics table
 
+// The dynamic-LDS limit of a kernel is a property of the kernel function, shared by every context of
+// the process, and contexts may plan and launch from several host threads (one per GPU, or several
+// on one GPU): the limit is only ever RAISED (a launch asks for what its own plan says, which the
+// limit then still allows), and planning is serialised.
+std::mutex g_lds_limit_mutex;
+std::map<std::pair<int, const void *>, int> g_lds_limit; // (device, kernel) -> limit set so far
+void raise_lds_limit(const void *kernel, int bytes)
+{
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    int &cur = g_lds_limit[{dev, kernel}];
+    if (bytes > cur)
+    {
+        HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        cur = bytes;
+    }
+}
+
 // dynamic LDS of a BVH kernel (its traversal stacks); large requests must be announced
 template <class K> inline void allow_dynamic_lds(K kernel, size_t bytes)
 {
     if (bytes > 0)
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+    {
+        std::lock_guard<std::mutex> lock(g_lds_limit_mutex);
+        raise_lds_limit(reinterpret_cast<const void *>(kernel), static_cast<int>(bytes));
+    }
 }
 
 inline unsigned blocks_for(int64_t n) { return static_cast<unsigned>(std::max<int64_t>(1, (n + BLOCK - 1) / BLOCK)); }
@@ -328,10 +351,10 @@ template <class R> struct Context::Impl
     {
         if (bytes <= state_mem.bytes)
             return;
-        DeviceBuffer bigger;
-        bigger.alloc(bytes);
-        std::swap(bigger.p, state_mem.p);
-        std::swap(bigger.bytes, state_mem.bytes);
+        // nothing in the region is live between two calls, and the caller's budget counts the old region
+        // as reusable: release it before the larger one is asked for
+        state_mem.release();
+        state_mem.alloc(bytes);
     }
 };
 
@@ -431,15 +454,33 @@ Context::Context(int device) : device_(device)
     HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void **>(&static_state_), HIP_SYMBOL(scratch)));
     // what a render call needs besides device memory is created here, not in the call: two events
     // and a pinned landing place for the statistics
-    HIP_CHECK(hipEventCreate(&ev_begin_));
-    HIP_CHECK(hipEventCreate(&ev_end_));
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&host_stats_), sizeof(unsigned long long) * 8, hipHostMallocDefault));
-    f64_ = new Impl<double>();
-    f32_ = new Impl<float>();
+    // (a constructor that throws runs no destructor: what was made so far is released here)
+    try
+    {
+        HIP_CHECK(hipEventCreate(&ev_begin_));
+        HIP_CHECK(hipEventCreate(&ev_end_));
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&host_stats_), sizeof(unsigned long long) * 8, hipHostMallocDefault));
+        f64_ = new Impl<double>();
+        f32_ = new Impl<float>();
+    }
+    catch (...)
+    {
+        if (ev_begin_)
+            (void)hipEventDestroy(ev_begin_);
+        if (ev_end_)
+            (void)hipEventDestroy(ev_end_);
+        if (host_stats_)
+            (void)hipHostFree(host_stats_);
+        delete f64_;
+        delete f32_;
+        throw;
+    }
 }
 
 Context::~Context()
 {
+    if (shard_)
+        free_shard_slot(shard_); // joins the context's worker thread, frees its frame buffers
     (void)hipSetDevice(device_);
     delete f64_;
     delete f32_;
@@ -637,6 +678,7 @@ struct BvhLdsPlan
 };
 static BvhLdsPlan plan_bvh_lds(const void *kernel, int want_per_cu, int stack_need, int lds_stack_cap, int n_nodes, int lds_nodes_opt)
 {
+    std::lock_guard<std::mutex> lock(g_lds_limit_mutex);
     BvhLdsPlan r;
     hipFuncAttributes fa;
     HIP_CHECK(hipFuncGetAttributes(&fa, kernel));
@@ -661,7 +703,7 @@ static BvhLdsPlan plan_bvh_lds(const void *kernel, int want_per_cu, int stack_ne
         int got = 0;
         while (dyn >= useful * level_bytes)
         {
-            HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+            raise_lds_limit(kernel, dyn);
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, kernel, BLOCK, static_cast<size_t>(dyn)));
             if (got >= b)
                 break;
@@ -692,7 +734,7 @@ static BvhLdsPlan plan_bvh_lds(const void *kernel, int want_per_cu, int stack_ne
     }
     r.levels = levels, r.nodes = nodes;
     r.dyn_bytes = static_cast<size_t>(levels) * level_bytes + static_cast<size_t>(nodes) * 64;
-    HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(r.dyn_bytes)));
+    raise_lds_limit(kernel, static_cast<int>(r.dyn_bytes));
     return r;
 }
 
@@ -966,7 +1008,10 @@ static TracePlan<R> plan_trace(const DScene<R> &S, int blocks_per_cu, bool shado
         p.lds_nodes = lp.nodes;
         p.dyn_lds = lp.dyn_bytes;
         if (p.wf_fast || p.wf_sq) // same registers, same LDS split
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(p.anyhit), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(p.dyn_lds)));
+            {
+                std::lock_guard<std::mutex> lock(g_lds_limit_mutex);
+                raise_lds_limit(reinterpret_cast<const void *>(p.anyhit), static_cast<int>(p.dyn_lds));
+            }
     }
     else if (per_cu <= 0)
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, p.kernel, BLOCK, 0));
@@ -995,7 +1040,7 @@ static void launch_trace(const TracePlan<R> &plan, const DScene<R> &S, const DCa
 // traversal kernel (the spill columns and the statistics rows were laid out for them).
 template <class R>
 static void launch_wavefront(const TracePlan<R> &plan, const DScene<R> &S, const DCamera &cam, const DBatch &B, Context::Impl<R> &im, hipStream_t s,
-                             int grid_blocks, int refill, unsigned long long *pinned_word)
+                             int grid_blocks, int refill, unsigned long long *pinned_word, bool may_wait)
 {
     DState<R> &st = im.st;
     st.n_waves = grid_blocks * (BLOCK / 64);
@@ -1008,7 +1053,7 @@ static void launch_wavefront(const TracePlan<R> &plan, const DScene<R> &S, const
         // Deep scenes: most paths end long before Depth.  From bounce 8 on, every eighth bounce reads
         // the count of the queue it is about to traverse back (4 bytes into pinned memory, one wait)
         // and stops when no ray is left; scenes of ordinary depth never get here.
-        if (b >= 8 && (b & 7) == 0)
+        if (may_wait && b >= 8 && (b & 7) == 0)
         {
             *pinned_word = 1ull;
             HIP_CHECK(hipMemcpyAsync(pinned_word, in.count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -1160,7 +1205,7 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
 
     auto S = make_dscene<R>(sc, *geo_, im.tri_pre.p, im.mats.p, im.lights.p, im.tri_nrm.p, im.bvh.p, brute_);
     DCamera cam = make_camera(sc);
-    RenderTimers *tm = (o.profile && !static_state) ? &timers_ : nullptr;
+    RenderTimers *tm = (o.profile && !static_state && !o.enqueue_only) ? &timers_ : nullptr;
     // The grid of the tracer is just large enough to fill the device: its waves are persistent.
     const bool fast = o.estimator == PTX_ESTIMATOR_FAST_;
     TracePlan<R> plan = brute_ ? plan_trace<R, true>(S, trace_blocks_per_cu, shadow_queue, 0, 0, false, fast)
@@ -1258,7 +1303,8 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
     HIP_CHECK(hipMemsetAsync(im.st.stats, 0, sizeof(unsigned long long) * 8, s));
     HIP_CHECK(hipMemsetAsync(im.st.pool, 0, sizeof(unsigned int), s));
 
-    HIP_CHECK(hipEventRecord(ev_begin_, s));
+    if (!o.enqueue_only)
+        HIP_CHECK(hipEventRecord(ev_begin_, s));
     uint64_t passes = 0;
     for (int lr0 = 0; lr0 < n_local_rows; lr0 += rows_per_chunk)
     {
@@ -1279,12 +1325,19 @@ template <class R> void Context::render_impl(Impl<R> &im, const RenderOpts &o, d
             if (tm)
                 tm->mark(s, RenderTimers::TRACE);
             if (plan.wavefront)
-                launch_wavefront<R>(plan, S, cam, B, im, s, grid_blocks, wf_refill, host_stats_ + 7);
+                launch_wavefront<R>(plan, S, cam, B, im, s, grid_blocks, wf_refill, host_stats_ + 7, !o.enqueue_only);
             else
                 launch_trace<R>(plan, S, cam, B, im.st, s, chunk, grid_blocks);
             launch_finish<R>(S, B, im.st, d_sum, s, tm);
             passes++;
         }
+    }
+    if (o.enqueue_only)
+    {
+        // nothing is waited for and nothing read back: the caller owns the stream (it may be capturing it)
+        stats.passes = passes;
+        stats.state_bytes = im.layout_state(nullptr, need, &spill);
+        return;
     }
     HIP_CHECK(hipEventRecord(ev_end_, s));
     HIP_CHECK(hipMemcpyAsync(host_stats_, im.st.stats, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, s)); // pinned: a plain DMA
@@ -1315,6 +1368,8 @@ void Context::render(const RenderOpts &o, double *sum, bool out_is_device, Rende
     const int64_t n = static_cast<int64_t>(scene_.width) * scene_.height;
     if (static_state && !out_is_device)
         throw std::runtime_error("arg: ptx_render_static writes to device memory only");
+    if (o.enqueue_only && !out_is_device)
+        throw std::runtime_error("arg: enqueue_only needs a device output buffer (a copy to the host would have to be waited for)");
     DeviceBuffer tmp;
     double *d_sum = sum;
     if (!out_is_device)

@@ -28,6 +28,7 @@ struct RenderOpts
     bool accumulate = false;
     bool profile = false;
     int estimator = PTX_ESTIMATOR_REFERENCE_;
+    bool enqueue_only = false; // no wait, no read-back, no statistics: the call only puts work on the stream
 };
 
 struct RenderStats
@@ -116,6 +117,10 @@ public:
 
     struct Geometry;
     template <class R> struct Impl;
+    // what the context keeps between frames rendered over several GPUs (sharded.hip): device buffers
+    // and the host thread that drives this GPU; made on first use, freed with the context
+    struct ShardSlot;
+    ShardSlot &shard_slot();
 
 private:
     void require_scene() const;
@@ -137,6 +142,8 @@ private:
     hipEvent_t ev_begin_ = nullptr, ev_end_ = nullptr;
     unsigned long long *host_stats_ = nullptr;  // pinned
     std::string last_kernel_;
+    ShardSlot *shard_ = nullptr;
+    static void free_shard_slot(ShardSlot *);
 };
 
 // One frame over n contexts (one per GPU, one host thread each) and the final reduce of the sums

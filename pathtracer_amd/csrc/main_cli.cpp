@@ -30,6 +30,7 @@ int main(int argc, char **argv)
     std::memset(&ov, 0, sizeof(ov));
     ptx_render_opts ro;
     std::memset(&ro, 0, sizeof(ro));
+    ro.struct_size = sizeof(ro);
     ro.seed = 13;
     std::string out_path, root;
     int gpu = 0;
@@ -111,6 +112,8 @@ int main(int argc, char **argv)
     ptx_context *ctx = ctxs[0];
     std::vector<double> sum(static_cast<size_t>(info.width) * info.height * 3), img(sum.size());
     ptx_stats st;
+    std::memset(&st, 0, sizeof(st));
+    st.struct_size = sizeof(st);
     if (ctxs.size() == 1)
     {
         if (ptx_render(ctx, &ro, sum.data(), 0, &st))
@@ -121,9 +124,10 @@ int main(int argc, char **argv)
         // interleaved row bands of 8 (or sample ranges), one host thread per GPU inside the library,
         // then the one exchange: the per-pixel sums reduced onto the first GPU
         std::vector<ptx_stats> per(ctxs.size());
+        std::memset(per.data(), 0, per.size() * sizeof(ptx_stats));
+        per[0].struct_size = sizeof(ptx_stats);
         if (ptx_render_sharded(ctxs.data(), static_cast<int32_t>(ctxs.size()), &ro, scheme, exchange, sum.data(), per.data()))
             return die("sharded render");
-        std::memset(&st, 0, sizeof(st));
         for (size_t k = 0; k < per.size(); k++)
         {
             std::printf("[log] gpu %d: %llu paths, %.3f ms\n", devices[k], (unsigned long long)per[k].paths, per[k].ms_total);

@@ -1,7 +1,11 @@
 // One frame over several GPUs of one node from a single process: one host thread and one context
 // per device, the frame cut by sample ranges or by interleaved row bands, and ONE exchange at the
-// end -- the reduce of the per-pixel radiance sums onto the first device, by RCCL (ncclReduce, f64
-// sum, over xGMI) or by peer copies added in device order.
+// end onto the first device.  Sample ranges: the per-pixel radiance sums of all contexts are reduced
+// (ncclReduce, f64 sum, over xGMI -- or peer copies added in context order): W * H * 24 bytes per
+// context.  Row bands: the supports are disjoint, so nothing is summed and only a context's own rows
+// travel, packed into one message of W * H * 24 / n bytes (ncclSend / ncclRecv in one group -- or one
+// peer copy each), and the first device puts them in place.  Frame buffers, packed rows, the landing
+// area and the host threads belong to the contexts and are reused from frame to frame.
 //
 // What is being sharded is the row loop of cPathTracer::RayTracing (src/tracing/cPathTracer.cpp:
 // 526-529 of the reference: OpenMP over rows inside one process); the per-pixel value is
@@ -14,6 +18,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -42,6 +49,8 @@ struct Rccl
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -63,6 +72,8 @@ struct Rccl
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
         Reduce = reinterpret_cast<decltype(Reduce)>(sym("ncclReduce"));
+        Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
@@ -86,27 +97,142 @@ __global__ void __launch_bounds__(256) k_add_sums(double *__restrict__ dst, cons
         dst[i] += src[i];
 }
 
+// Rows of the interleaved bands of one owner: band b (rows [b * band, b * band + band)) belongs to
+// owner b mod n.  Packed layout: the owner's rows in ascending order, one after the other.
+// pack: frame -> packed (TO_PACKED) or packed -> frame; row_vals = 3 * width doubles per row.
+template <bool TO_PACKED>
+__global__ void __launch_bounds__(256) k_band_rows(double *__restrict__ frame, double *__restrict__ packed, int height, int64_t row_vals, int band,
+                                                   int n_owners, int owner, int64_t packed_rows)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= packed_rows * row_vals)
+        return;
+    const int64_t pr = i / row_vals, c = i % row_vals;
+    // packed row pr: the (pr / band)-th band of this owner, row pr % band of it
+    const int64_t b = (pr / band) * n_owners + owner;
+    const int64_t row = b * band + pr % band;
+    if (row >= height)
+        return;
+    if (TO_PACKED)
+        packed[i] = frame[row * row_vals + c];
+    else
+        frame[row * row_vals + c] = packed[i];
+}
+
+// rows of the frame that owner `i` of `n` renders
+int64_t rows_of_owner(int height, int band, int n, int i)
+{
+    int64_t rows = 0;
+    for (int64_t b = i; b * band < height; b += n)
+        rows += std::min<int64_t>(band, height - b * band);
+    return rows;
+}
+
 struct Buffer
 {
     void *p = nullptr;
     int dev = 0;
-    void alloc(int device, size_t bytes)
+    size_t bytes = 0;
+    // grows, never shrinks: a frame loop allocates on its first frame only
+    void ensure(int device, size_t need)
     {
+        if (p && bytes >= need && dev == device)
+            return;
+        release();
         dev = device;
         HIP_CHECK(hipSetDevice(device));
-        HIP_CHECK(hipMalloc(&p, bytes));
+        HIP_CHECK(hipMalloc(&p, need));
+        bytes = need;
     }
-    ~Buffer()
+    void release()
     {
         if (p)
         {
             (void)hipSetDevice(dev);
             (void)hipFree(p);
         }
+        p = nullptr, bytes = 0;
     }
+    ~Buffer() { release(); }
 };
 
 } // namespace
+
+// What a context keeps between sharded frames: its frame of sums, its packed bands, on the first
+// device the landing area of the others' data, and the host thread that drives its GPU.  Made at the
+// context's first sharded frame, freed with the context.
+struct Context::ShardSlot
+{
+    Buffer frame, packed, stage;
+    std::thread worker;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = true, stop = false;
+    std::string error;
+
+    ShardSlot()
+    {
+        worker = std::thread([this]() {
+            std::unique_lock<std::mutex> lk(m);
+            for (;;)
+            {
+                cv.wait(lk, [this]() { return has_job || stop; });
+                if (stop)
+                    return;
+                std::function<void()> j = std::move(job);
+                has_job = false;
+                lk.unlock();
+                std::string e;
+                try
+                {
+                    j();
+                }
+                catch (const std::exception &ex)
+                {
+                    e = ex.what();
+                }
+                lk.lock();
+                error = e;
+                done = true;
+                cv.notify_all();
+            }
+        });
+    }
+    void start(std::function<void()> j)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        job = std::move(j);
+        has_job = true, done = false;
+        error.clear();
+        cv.notify_all();
+    }
+    std::string wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this]() { return done; });
+        return error;
+    }
+    ~ShardSlot()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+            cv.notify_all();
+        }
+        if (worker.joinable())
+            worker.join();
+    }
+};
+
+void Context::free_shard_slot(ShardSlot *s) { delete s; }
+
+Context::ShardSlot &Context::shard_slot()
+{
+    if (!shard_)
+        shard_ = new ShardSlot();
+    return *shard_;
+}
 
 void render_sharded(Context *const *ctxs, int n, const RenderOpts &base, int scheme, int exchange, double *rgb_sum, RenderStats *stats)
 {
@@ -119,6 +245,9 @@ void render_sharded(Context *const *ctxs, int n, const RenderOpts &base, int sch
         if (ctxs[i]->scene().width != ctxs[0]->scene().width || ctxs[i]->scene().height != ctxs[0]->scene().height ||
             ctxs[i]->scene().spp != ctxs[0]->scene().spp)
             throw std::runtime_error("arg: the contexts hold scenes of different sizes");
+        for (int j = 0; j < i; j++)
+            if (ctxs[i] == ctxs[j])
+                throw std::runtime_error("arg: the same context twice");
     }
     if (exchange == PTX_EXCHANGE_RCCL)
         for (int i = 0; i < n; i++)
@@ -126,54 +255,86 @@ void render_sharded(Context *const *ctxs, int n, const RenderOpts &base, int sch
                 if (ctxs[i]->device() == ctxs[j]->device())
                     throw std::runtime_error("arg: an RCCL communicator takes every device once (two contexts share a GPU: use peer copies)");
     const Scene &sc = ctxs[0]->scene();
-    const int64_t n_val = static_cast<int64_t>(sc.width) * sc.height * 3;
+    const int64_t row_vals = static_cast<int64_t>(sc.width) * 3;
+    const int64_t n_val = row_vals * sc.height;
     const size_t bytes = static_cast<size_t>(n_val) * sizeof(double);
     const int spp = base.spp > 0 ? base.spp : sc.spp; // samples of the whole frame
-    std::vector<Buffer> buf(n);
-    std::vector<std::string> err(n);
-    std::vector<std::thread> th;
+    const int band = base.band > 0 ? base.band : 8;
+    const bool bands = scheme == PTX_SHARD_BANDS;
+    std::vector<Context::ShardSlot *> slot(n);
     for (int i = 0; i < n; i++)
-        th.emplace_back([&, i]() {
-            try
+        slot[i] = &ctxs[i]->shard_slot();
+    // bands: every context owns the rows of its bands and only those travel -- packed, one message of
+    // rows_i * W * 24 bytes per context; sample ranges: whole frames are summed
+    std::vector<int64_t> rows(n, 0), row_off(n, 0);
+    if (bands)
+        for (int i = 0; i < n; i++)
+        {
+            rows[i] = rows_of_owner(sc.height, band, n, i);
+            row_off[i] = i ? row_off[i - 1] + rows[i - 1] : 0;
+        }
+    for (int i = 0; i < n; i++)
+        slot[i]->start([&, i]() {
+            Context::ShardSlot &me = *slot[i];
+            me.frame.ensure(ctxs[i]->device(), bytes);
+            RenderOpts o = base;
+            o.accumulate = false;
+            o.spp_total = base.spp_total > 0 ? base.spp_total : spp;
+            o.row_stride = 1, o.row_phase = 0, o.band = 1; // the caller's interleave, if any, is not this call's
+            if (!bands)
             {
-                buf[i].alloc(ctxs[i]->device(), bytes);
-                RenderOpts o = base;
-                o.accumulate = false;
-                o.spp_total = base.spp_total > 0 ? base.spp_total : spp;
-                if (scheme == PTX_SHARD_SAMPLES)
-                {
-                    // contiguous sample ranges that tile [0, spp)
-                    const int q = spp / n, r = spp % n;
-                    o.spp = q + (i < r ? 1 : 0);
-                    o.sample_offset = base.sample_offset + i * q + (i < r ? i : r);
-                }
-                else
-                {
-                    o.spp = spp;
-                    o.row_stride = n, o.row_phase = i, o.band = base.band > 0 ? base.band : 8;
-                }
-                RenderStats st;
-                if (o.spp > 0)
-                    ctxs[i]->render(o, static_cast<double *>(buf[i].p), true, st);
-                else
-                    HIP_CHECK(hipMemsetAsync(buf[i].p, 0, bytes, static_cast<hipStream_t>(ctxs[i]->stream())));
-                HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(ctxs[i]->stream())));
-                if (stats)
-                    stats[i] = st;
+                // contiguous sample ranges that tile [0, spp)
+                const int q = spp / n, r = spp % n;
+                o.spp = q + (i < r ? 1 : 0);
+                o.sample_offset = base.sample_offset + i * q + (i < r ? i : r);
             }
-            catch (const std::exception &e)
+            else
             {
-                err[i] = e.what();
+                o.spp = spp;
+                o.row_stride = n, o.row_phase = i, o.band = band;
             }
+            hipStream_t st_i = static_cast<hipStream_t>(ctxs[i]->stream());
+            RenderStats st;
+            if (o.spp > 0)
+                ctxs[i]->render(o, static_cast<double *>(me.frame.p), true, st);
+            else
+                HIP_CHECK(hipMemsetAsync(me.frame.p, 0, bytes, st_i));
+            if (bands && i > 0 && rows[i] > 0)
+            {
+                me.packed.ensure(ctxs[i]->device(), static_cast<size_t>(rows[i] * row_vals) * sizeof(double));
+                const int64_t nv = rows[i] * row_vals;
+                hipLaunchKernelGGL(k_band_rows<true>, dim3(static_cast<unsigned>((nv + 255) / 256)), dim3(256), 0, st_i, static_cast<double *>(me.frame.p),
+                                   static_cast<double *>(me.packed.p), sc.height, row_vals, band, n, i, rows[i]);
+                HIP_CHECK(hipGetLastError());
+            }
+            HIP_CHECK(hipStreamSynchronize(st_i));
+            if (stats)
+                stats[i] = st;
         });
-    for (auto &t : th)
-        t.join();
+    std::string first_error;
     for (int i = 0; i < n; i++)
-        if (!err[i].empty())
-            throw std::runtime_error(err[i]);
+    {
+        const std::string e = slot[i]->wait();
+        if (first_error.empty() && !e.empty())
+            first_error = e;
+    }
+    if (!first_error.empty())
+        throw std::runtime_error(first_error);
 
-    // ---- the one exchange: sums of all devices -> device of context 0 ---------------------------
+    // ---- the one exchange: -> device of context 0 ------------------------------------------------
     hipStream_t s0 = static_cast<hipStream_t>(ctxs[0]->stream());
+    Context::ShardSlot &root = *slot[0];
+    auto unpack_on_root = [&]() {
+        // the others' bands from the landing area into the root's frame (its own rows are there already)
+        for (int i = 1; i < n; i++)
+            if (rows[i] > 0)
+            {
+                const int64_t nv = rows[i] * row_vals;
+                hipLaunchKernelGGL(k_band_rows<false>, dim3(static_cast<unsigned>((nv + 255) / 256)), dim3(256), 0, s0, static_cast<double *>(root.frame.p),
+                                   static_cast<double *>(root.stage.p) + row_off[i] * row_vals, sc.height, row_vals, band, n, i, rows[i]);
+                HIP_CHECK(hipGetLastError());
+            }
+    };
     if (exchange == PTX_EXCHANGE_RCCL) // also for a single context: a communicator of one, so that the same calls run
     {
         std::lock_guard<std::mutex> lock(g_rccl_mutex);
@@ -190,15 +351,39 @@ void render_sharded(Context *const *ctxs, int n, const RenderOpts &base, int sch
             g_rccl.check(g_rccl.CommInitAll(g_comms.data(), n, devs.data()), "ncclCommInitAll");
             g_comm_devs = devs;
         }
-        g_rccl.check(g_rccl.GroupStart(), "ncclGroupStart");
-        for (int i = 0; i < n; i++)
+        if (bands && n > 1)
         {
-            HIP_CHECK(hipSetDevice(devs[i]));
-            g_rccl.check(g_rccl.Reduce(buf[i].p, buf[i].p, static_cast<size_t>(n_val), ncclDouble, ncclSum, 0, g_comms[i],
-                                       static_cast<hipStream_t>(ctxs[i]->stream())),
-                         "ncclReduce");
+            // gather of disjoint bands: every context sends its packed rows to rank 0, which receives
+            // them side by side; one group, point to point over xGMI (seven peers, seven links)
+            HIP_CHECK(hipSetDevice(devs[0]));
+            root.stage.ensure(devs[0], bytes);
+            g_rccl.check(g_rccl.GroupStart(), "ncclGroupStart");
+            for (int i = 1; i < n; i++)
+            {
+                if (rows[i] <= 0)
+                    continue;
+                const size_t count = static_cast<size_t>(rows[i] * row_vals);
+                HIP_CHECK(hipSetDevice(devs[0]));
+                g_rccl.check(g_rccl.Recv(static_cast<double *>(root.stage.p) + row_off[i] * row_vals, count, ncclDouble, i, g_comms[0], s0), "ncclRecv");
+                HIP_CHECK(hipSetDevice(devs[i]));
+                g_rccl.check(g_rccl.Send(slot[i]->packed.p, count, ncclDouble, 0, g_comms[i], static_cast<hipStream_t>(ctxs[i]->stream())), "ncclSend");
+            }
+            g_rccl.check(g_rccl.GroupEnd(), "ncclGroupEnd");
+            HIP_CHECK(hipSetDevice(devs[0]));
+            unpack_on_root();
         }
-        g_rccl.check(g_rccl.GroupEnd(), "ncclGroupEnd");
+        else
+        {
+            g_rccl.check(g_rccl.GroupStart(), "ncclGroupStart");
+            for (int i = 0; i < n; i++)
+            {
+                HIP_CHECK(hipSetDevice(devs[i]));
+                g_rccl.check(g_rccl.Reduce(slot[i]->frame.p, slot[i]->frame.p, static_cast<size_t>(n_val), ncclDouble, ncclSum, 0, g_comms[i],
+                                           static_cast<hipStream_t>(ctxs[i]->stream())),
+                             "ncclReduce");
+            }
+            g_rccl.check(g_rccl.GroupEnd(), "ncclGroupEnd");
+        }
         for (int i = 0; i < n; i++)
         {
             HIP_CHECK(hipSetDevice(devs[i]));
@@ -207,20 +392,30 @@ void render_sharded(Context *const *ctxs, int n, const RenderOpts &base, int sch
     }
     else if (n > 1)
     {
-        // peer copies into a staging buffer on device 0, added in device order (a fixed sum order)
-        Buffer stage;
-        stage.alloc(ctxs[0]->device(), bytes);
-        for (int i = 1; i < n; i++)
+        HIP_CHECK(hipSetDevice(ctxs[0]->device()));
+        root.stage.ensure(ctxs[0]->device(), bytes);
+        if (bands)
         {
-            HIP_CHECK(hipMemcpyPeerAsync(stage.p, ctxs[0]->device(), buf[i].p, ctxs[i]->device(), bytes, s0));
-            hipLaunchKernelGGL(k_add_sums, dim3(static_cast<unsigned>((n_val + 255) / 256)), dim3(256), 0, s0,
-                               static_cast<double *>(buf[0].p), static_cast<const double *>(stage.p), n_val);
-            HIP_CHECK(hipGetLastError());
+            // peer copies of the packed bands into the landing area, then one unpack each
+            for (int i = 1; i < n; i++)
+                if (rows[i] > 0)
+                    HIP_CHECK(hipMemcpyPeerAsync(static_cast<double *>(root.stage.p) + row_off[i] * row_vals, ctxs[0]->device(), slot[i]->packed.p,
+                                                 ctxs[i]->device(), static_cast<size_t>(rows[i] * row_vals) * sizeof(double), s0));
+            unpack_on_root();
         }
+        else
+            // whole frames into the landing area one after the other, added in context order (a fixed sum order)
+            for (int i = 1; i < n; i++)
+            {
+                HIP_CHECK(hipMemcpyPeerAsync(root.stage.p, ctxs[0]->device(), slot[i]->frame.p, ctxs[i]->device(), bytes, s0));
+                hipLaunchKernelGGL(k_add_sums, dim3(static_cast<unsigned>((n_val + 255) / 256)), dim3(256), 0, s0,
+                                   static_cast<double *>(root.frame.p), static_cast<const double *>(root.stage.p), n_val);
+                HIP_CHECK(hipGetLastError());
+            }
         HIP_CHECK(hipStreamSynchronize(s0));
     }
     HIP_CHECK(hipSetDevice(ctxs[0]->device()));
-    HIP_CHECK(hipMemcpyAsync(rgb_sum, buf[0].p, bytes, hipMemcpyDeviceToHost, s0));
+    HIP_CHECK(hipMemcpyAsync(rgb_sum, root.frame.p, bytes, hipMemcpyDeviceToHost, s0));
     HIP_CHECK(hipStreamSynchronize(s0));
 }
 

@@ -1,6 +1,8 @@
 """Multi-GPU sharding of one frame: one process per GPU, no collective on the data path, ONE
-exchange at the end (reduce of the per-pixel radiance sums onto rank 0; RCCL over xGMI when the
-process group's backend is "nccl").
+exchange at the end onto rank 0 (RCCL over xGMI when the process group's backend is "nccl"):
+sample ranges -> reduce(sum) of the per-pixel radiance sums, W * H * 24 bytes per rank; row bands ->
+gather of every rank's own rows, packed, W * H * 24 / world bytes per rank (disjoint supports:
+nothing to add, and the frame is the single-GPU frame bit for bit).
 
 The per-pixel value of the reference is  sum_s final_s / spp  followed by one clamp
 (src/tracing/cPathTracer.cpp:692,701-702 of the reference), i.e. linear in the samples before the
@@ -21,6 +23,35 @@ def shard_samples(spp_total, rank, world):
 def shard_bands(rank, world, band=8):
     """Interleaved row bands: rank renders rows r with (r // band) % world == rank."""
     return dict(row_stride=int(world), row_phase=int(rank), band=int(band))
+
+
+def band_rows(height, rank, world, band=8):
+    """Rows of the frame that `rank` renders under shard_bands, ascending (a list of ints)."""
+    return [r for r in range(int(height)) if (r // int(band)) % int(world) == int(rank)]
+
+
+def gather_bands(out, rank, world, band=8):
+    """The exchange of the bands scheme: every rank sends ITS rows of `out` ([H, W, 3] float64), packed
+    into one message (padded to the largest share so that all messages have one size), rank 0 puts
+    them in place.  W * H * 24 / world bytes per rank instead of the whole frame."""
+    import torch
+    import torch.distributed as dist
+    H = out.shape[0]
+    flat = out.view(H, -1)
+    share = [band_rows(H, r, world, band) for r in range(world)]
+    most = max(len(x) for x in share)
+    packed = torch.zeros((most, flat.shape[1]), dtype=out.dtype, device=out.device)
+    mine = torch.tensor(share[rank], dtype=torch.long, device=out.device)
+    if len(share[rank]):
+        packed[: len(share[rank])] = flat.index_select(0, mine)
+    if rank == 0:
+        parts = [torch.empty_like(packed) for _ in range(world)]
+        dist.gather(packed, gather_list=parts, dst=0)
+        for r in range(1, world):
+            if len(share[r]):
+                flat.index_copy_(0, torch.tensor(share[r], dtype=torch.long, device=out.device), parts[r][: len(share[r])])
+    else:
+        dist.gather(packed, dst=0)
 
 
 def render_frame(render_fn, out, spp_total, rank=0, world=1, scheme="samples", band=8, reduce=True,
@@ -44,19 +75,26 @@ def render_frame(render_fn, out, spp_total, rank=0, world=1, scheme="samples", b
         raise ValueError("scheme must be 'samples' or 'bands'")
     if reduce and (world > 1 if collective is None else collective):
         import torch.distributed as dist
+
+        def exchange():
+            if scheme == "bands":
+                gather_bands(out, rank, world, band)
+            else:
+                dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+
         if reduce_ms is None:
-            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+            exchange()
         elif out.is_cuda:
             import torch
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+            exchange()
             e1.record()
             e1.synchronize()
             reduce_ms.append(e0.elapsed_time(e1))
         else:
             import time
             t0 = time.perf_counter()
-            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+            exchange()
             reduce_ms.append((time.perf_counter() - t0) * 1e3)
     return stats

@@ -36,6 +36,27 @@ def test_sharded_render_equals_single_render(root, conf, kw):
     assert np.array_equal(f32, ctxs[0].render(mode="f32")[0])
 
 
+def test_band_gather_ragged_frames_and_reuse(root):
+    """Row bands: only a context's own rows travel (packed, one message per context) and the first
+    context puts them in place -- whatever the height (not a multiple of band x contexts, fewer bands
+    than contexts), the band height and the number of contexts, and frame after frame on the same
+    contexts (their buffers and host threads are kept): always the single-context frame bit for bit."""
+    import json
+    base = json.load(open(os.path.join(root, "config/cbox.conf")))
+    for w, h in ((40, 61), (24, 13), (56, 96), (16, 7)):          # the larger frame after smaller ones and back
+        s, _ = load(root, "config/cbox.conf", width=w, height=h, spp=3)
+        ctxs = [make_ctx(s) for _ in range(4)]
+        full, st = ctxs[0].render(mode="f64")
+        for n, band in ((4, 8), (3, 5), (2, 1), (4, 3)):
+            for _ in range(2):                                     # twice: the second frame reuses everything
+                img, sb = pt.render_sharded(ctxs[:n], scheme="bands", exchange="peer", band=band)
+                assert np.array_equal(img, full), (w, h, n, band)
+                assert sum(x["paths"] for x in sb) == st["paths"]
+        # a caller's own interleave options do not leak into the sharded call
+        o_img, _ = pt.render_sharded(ctxs[:2], scheme="samples", exchange="peer")
+        assert np.abs(o_img - full).max() <= 1e-14 * max(1.0, full.max())
+
+
 def test_rccl_exchange_with_a_communicator_of_one(root):
     s, _ = load(root, "config/cbox.conf", width=64, height=64, spp=4)
     c = make_ctx(s)

@@ -99,3 +99,44 @@ def test_static_state_render_rejects_what_does_not_fit(root):
     with pytest.raises(pt.PtxError):
         _lib_null = pt.lib().ptx_render_static(c._h, None, None, None)
         pt._lib.check(_lib_null)
+
+
+@pytest.mark.parametrize("conf,kw,depth", [("config/cbox.conf", dict(width=96, height=80, spp=4), None),
+                                           ("config/mis.conf", dict(width=96, height=64, spp=3), None),
+                                           ("config/mis.conf", dict(width=48, height=32, spp=2), 20)])
+def test_static_render_under_stream_capture(root, conf, kw, depth):
+    """opts.enqueue_only: ptx_render_static neither waits for its stream nor reads anything back, so a
+    stream capture takes it -- the all-triangles tracer, the wavefront tracer of a BVH scene, and that
+    tracer at a depth where it would otherwise read a queue count back every eighth bounce.  The
+    captured graph is launched twice; both frames equal ptx_render's bit for bit."""
+    s, _ = load(root, conf, **kw)
+    c = make_ctx(s)
+    H, W = kw["height"], kw["width"]
+    want, _ = c.render(mode="f64", depth=depth)
+    out = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+    c.render_static(out.data_ptr(), mode="f64", depth=depth)               # kernels loaded, LDS limits set: not part of the capture
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    c.set_stream(side.cuda_stream)
+    try:
+        with torch.cuda.graph(g, stream=side):
+            st = c.render_static(out.data_ptr(), mode="f64", depth=depth, enqueue_only=True)
+    finally:
+        c.set_stream(None)
+    assert st["paths"] == 0 and st["passes"] >= 1 and st["state_bytes"] > 0   # no statistics came back: nothing was waited for
+    for _ in range(2):
+        out.fill_(-1.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+    # outside a capture the flag only drops the wait: the frame is there once the stream is done
+    out.fill_(-1.0)
+    c.render_static(out.data_ptr(), mode="f64", depth=depth, enqueue_only=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    import ctypes
+    host = np.zeros((H, W, 3))
+    o = c._opts("f64", None, 0, None, None, 1, 0, 1, None, 13, None, False, False, "reference", True)
+    rc = pt.lib().ptx_render(c._h, ctypes.byref(o), ctypes.c_void_p(host.ctypes.data), 0, None)
+    assert rc == 1 and b"enqueue_only" in pt.lib().ptx_last_error()       # a host buffer would have to be waited for
