@@ -6,6 +6,13 @@ Command line:  python -m pathtracer_amd.image A.ppm [B.ppm] [--tolerance T]
 prints one JSON object (relative MSE -- the measure of the parity bar --, PSNR, CIE76 colour
 difference, a FLIP-like perceptual mean); with two images the exit code is 1 when the relative MSE
 exceeds T.
+
+               python -m pathtracer_amd.image --merge A.part B.part ... -o out.ppm
+adds parts of one frame written by `pathtracer <conf> --dump-partial FILE [--rows A:B] [--samples A:B]`
+(the pre-clamp sums of some rows and some samples: a long render cut into pieces, done piece by piece,
+resumed where it stopped), applies the final clamp and writes the reference's PPM.  Parts that
+overlap, disagree about the frame (size, sample count, depth, seed, precision, estimator) or do not
+add up to the whole frame are refused.
 """
 import json
 import sys
@@ -101,8 +108,86 @@ def merge_partial_sums(parts):
     return out
 
 
+PART_MAGIC = b"PTXPART1"
+
+
+def write_part(path, rows_sum, width, height, spp_total, rows, samples, mode=0, estimator=0, depth=0, seed=13):
+    """A part file as the command line writes it: rows_sum = [rows[1] - rows[0], width, 3] float64."""
+    a = np.ascontiguousarray(rows_sum, dtype="<f8")
+    if a.shape != (rows[1] - rows[0], width, 3):
+        raise ValueError("rows_sum has shape %s, the header says %s" % (a.shape, (rows[1] - rows[0], width, 3)))
+    head = np.array([width, height, spp_total, rows[0], rows[1], samples[0], samples[1], mode, estimator, depth, 0, 0], dtype="<i4")
+    with open(path, "wb") as f:
+        f.write(PART_MAGIC)
+        f.write(head.tobytes())
+        f.write(np.array([seed], dtype="<u8").tobytes())
+        f.write(a.tobytes())
+
+
+def read_part(path):
+    """(header dict, rows_sum [n_rows, width, 3]) of a part file; raises ValueError on a malformed one."""
+    with open(path, "rb") as f:
+        blob = f.read()
+    if len(blob) < 64 or blob[:8] != PART_MAGIC:
+        raise ValueError("%s is not a partial-sum file" % path)
+    h = np.frombuffer(blob, dtype="<i4", count=12, offset=8)
+    head = dict(width=int(h[0]), height=int(h[1]), spp_total=int(h[2]), rows=(int(h[3]), int(h[4])), samples=(int(h[5]), int(h[6])),
+                mode=int(h[7]), estimator=int(h[8]), depth=int(h[9]), seed=int(np.frombuffer(blob, dtype="<u8", count=1, offset=56)[0]))
+    r0, r1 = head["rows"]
+    s0, s1 = head["samples"]
+    if not (0 <= r0 < r1 <= head["height"] and 0 <= s0 < s1 <= head["spp_total"] and head["width"] > 0):
+        raise ValueError("%s: ranges outside the frame it names" % path)
+    n = (r1 - r0) * head["width"] * 3
+    if len(blob) != 64 + 8 * n:
+        raise ValueError("%s: %d bytes of sums, the header promises %d" % (path, len(blob) - 64, 8 * n))
+    return head, np.frombuffer(blob, dtype="<f8", count=n, offset=64).reshape(r1 - r0, head["width"], 3)
+
+
+def merge_parts(paths):
+    """The whole frame's pre-clamp sums [H, W, 3] from part files.  Every (row, sample) of the frame must
+    be covered exactly once: parts are rectangles of rows x samples, and they must agree about the frame.
+    Parts of the same rows are added in ascending sample order (the order a single render adds them in)."""
+    parts = [read_part(p) + (p,) for p in paths]
+    if not parts:
+        raise ValueError("no parts")
+    first = parts[0][0]
+    for head, _, path in parts:
+        for k in ("width", "height", "spp_total", "mode", "estimator", "depth", "seed"):
+            if head[k] != first[k]:
+                raise ValueError("%s: %s is %s, %s says %s" % (path, k, head[k], parts[0][2], first[k]))
+    H, W, S = first["height"], first["width"], first["spp_total"]
+    cover = np.zeros((H, S), dtype=np.int32)                    # how many parts hold (row, sample)
+    for head, _, path in parts:
+        (r0, r1), (s0, s1) = head["rows"], head["samples"]
+        if cover[r0:r1, s0:s1].any():
+            raise ValueError("%s overlaps another part (rows %d:%d, samples %d:%d)" % (path, r0, r1, s0, s1))
+        cover[r0:r1, s0:s1] += 1
+    if not cover.all():
+        r, s = np.argwhere(cover == 0)[0]
+        raise ValueError("the parts do not cover the frame: row %d, sample %d is in none of them" % (r, s))
+    out = np.zeros((H, W, 3))
+    for head, rows_sum, _ in sorted(parts, key=lambda t: t[0]["samples"][0]):
+        out[head["rows"][0]:head["rows"][1]] += rows_sum
+    return out, first
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
+    if argv and argv[0] == "--merge":
+        if "-o" not in argv or argv.index("-o") + 1 >= len(argv):
+            print("usage: python -m pathtracer_amd.image --merge A.part B.part ... -o out.ppm")
+            return 2
+        i = argv.index("-o")
+        out_path, paths = argv[i + 1], argv[1:i] + argv[i + 2:]
+        from .api import finalize_image, write_ppm
+        try:
+            total, head = merge_parts(paths)
+        except (ValueError, OSError) as e:
+            print("[error] %s" % e)
+            return 1
+        write_ppm(out_path, finalize_image(total))
+        print(json.dumps({"merged": len(paths), "width": head["width"], "height": head["height"], "spp_total": head["spp_total"], "out": out_path}))
+        return 0
     tol = None
     if "--tolerance" in argv:
         i = argv.index("--tolerance")

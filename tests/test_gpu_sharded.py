@@ -85,3 +85,45 @@ def test_command_line_shards_over_devices(root, tmp_path):
     assert np.abs(outs["one"] - outs["samples"]).max() <= 1            # int(c * 255) of sums that differ by an ulp
     p = subprocess.run(base + ["--devices", "0,7"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert p.returncode == 1 and "[error]" in p.stdout                  # the reference's error convention
+
+
+def test_dumped_parts_merge_to_the_one_piece_ppm(root, tmp_path):
+    """`pathtracer <conf> --dump-partial FILE --rows A:B | --samples A:B` writes the pre-clamp sums of a
+    part of the frame; `python -m pathtracer_amd.image --merge` adds the parts, clamps and writes the
+    PPM.  Two row halves (and four quarters: rows x samples cut at the batch boundaries a single render
+    has) give the one-piece file byte for byte; a missing part is refused."""
+    import sys
+    from pathtracer_amd import image
+    exe = os.path.join(root, "pathtracer_amd", "pathtracer")
+    base = [exe, "config/mis.conf", "--width", "72", "--height", "56", "--spp", "6"]
+
+    def run(extra):
+        p = subprocess.run(base + extra, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout
+        return p.stdout
+
+    whole = tmp_path / "whole.ppm"
+    run(["--out", str(whole)])
+    parts = {}
+    for name, extra in (("top", ["--rows", "0:24"]), ("bottom", ["--rows", "24:56"]),
+                        ("q0", ["--rows", "0:24", "--samples", "0:4"]), ("q1", ["--rows", "0:24", "--samples", "4:6"]),
+                        ("q2", ["--rows", "24:56", "--samples", "0:1"]), ("q3", ["--rows", "24:56", "--samples", "1:6"])):
+        parts[name] = str(tmp_path / (name + ".part"))
+        assert "rows" in run(["--dump-partial", parts[name]] + extra)
+    merge = [sys.executable, "-m", "pathtracer_amd.image", "--merge"]
+    out = tmp_path / "halves.ppm"
+    p = subprocess.run(merge + [parts["top"], parts["bottom"], "-o", str(out)], cwd=root, stdout=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout
+    assert open(out, "rb").read() == open(whole, "rb").read()                 # byte for byte
+    out4 = tmp_path / "quarters.ppm"
+    p = subprocess.run(merge + [parts[k] for k in ("q3", "q0", "q2", "q1")] + ["-o", str(out4)], cwd=root, stdout=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout
+    a, b = pt.read_ppm(str(out4)), pt.read_ppm(str(whole))
+    assert np.abs(a - b).max() <= 1 and (a != b).mean() < 1e-3               # sample ranges added apart: sums differ by an ulp at most
+    total, head = image.merge_parts([parts["top"], parts["bottom"]])
+    s, _ = load(root, "config/mis.conf", width=72, height=56, spp=6)
+    assert np.array_equal(total, make_ctx(s).render(mode="f64")[0]) and head["depth"] == 5
+    p = subprocess.run(merge + [parts["top"], parts["q2"], "-o", str(out)], cwd=root, stdout=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 1 and "[error]" in p.stdout
+    p = subprocess.run(base + ["--rows", "0:10"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert p.returncode == 1 and "--dump-partial" in p.stdout

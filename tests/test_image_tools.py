@@ -92,3 +92,40 @@ def test_colour_difference_and_perceptual_map():
     assert image.flip_lite(noisy, a).mean() < image.flip_lite(shifted, a).mean()
     c = image.compare((a * 255).astype(np.int64), (shifted * 255).astype(np.int64))
     assert {"delta_e76_mean", "delta_e76_p95", "delta_e76_max", "flip_lite_mean"} <= set(c) and c["delta_e76_mean"] > 0
+
+
+def test_merge_of_part_files(tmp_path):
+    """Part files (the pre-clamp sums of some rows x some samples of a frame, `pathtracer --dump-partial`)
+    merge to the frame only when they tile it: overlaps, holes and parts of another frame are refused."""
+    from pathtracer_amd import image
+    rng = np.random.default_rng(5)
+    H, W, S = 12, 7, 8
+    per_sample = rng.uniform(0, 2, (S, H, W, 3)) / S          # what each sample adds to the sums
+    full = per_sample.sum(0)
+
+    def part(name, rows, samples, **kw):
+        p = str(tmp_path / name)
+        image.write_part(p, per_sample[samples[0]:samples[1], rows[0]:rows[1]].sum(0), W, H, S, rows, samples, depth=5, **kw)
+        return p
+
+    a, b = part("top", (0, 5), (0, S)), part("bottom", (5, H), (0, S))
+    total, head = image.merge_parts([b, a])
+    assert np.allclose(total, full, rtol=0, atol=1e-15) and (head["width"], head["height"], head["spp_total"]) == (W, H, S)
+    quads = [part("q%d" % i, r, s) for i, (r, s) in enumerate([((0, 5), (0, 3)), ((0, 5), (3, S)), ((5, H), (0, 6)), ((5, H), (6, S))])]
+    assert np.allclose(image.merge_parts(quads)[0], full, rtol=0, atol=1e-15)
+    h, rows_sum = image.read_part(a)
+    assert h["rows"] == (0, 5) and h["samples"] == (0, S) and h["seed"] == 13 and rows_sum.shape == (5, W, 3)
+    for bad, why in (([a], "cover"), ([a, b, quads[0]], "overlaps"), ([a, part("other_seed", (5, H), (0, S), seed=14)], "seed"),
+                     ([a, part("f32", (5, H), (0, S), mode=1)], "mode"), ([quads[0], quads[2], quads[3]], "cover")):
+        with pytest.raises(ValueError) as e:
+            image.merge_parts(bad)
+        assert why in str(e.value)
+    (tmp_path / "junk").write_bytes(b"P3\n1 1\n255\n0 0 0 ")
+    with pytest.raises(ValueError):
+        image.read_part(str(tmp_path / "junk"))
+    open(a, "ab").write(b"\0" * 8)                              # a truncated or padded file is not read
+    with pytest.raises(ValueError):
+        image.read_part(a)
+    # the command line: exit code 1 and the reference's "[error]" convention on a refusal, 2 on misuse
+    assert image.main(["--merge", b, "-o", str(tmp_path / "x.ppm")]) == 1
+    assert image.main(["--merge", b]) == 2
