@@ -143,6 +143,9 @@ template <class R> __device__ __forceinline__ R *record_at(const DState<R> &st, 
 // including the rounding of the ray and of the record to f32).
 // ---------------------------------------------------------------------------------------------
 constexpr int PQ_STRIDE = 32;
+#ifndef PTX_PQ_WIDE_LOADS
+#define PTX_PQ_WIDE_LOADS 1
+#endif
 constexpr int BRUTE_MAX_TRIS = 64; // candidate mask is one 64-bit word ...
 constexpr int BRUTE_MAX_RECS = 32; // ... of two bits per record
 
@@ -195,8 +198,8 @@ __device__ __forceinline__ unsigned long long prefilter_mask(const float *__rest
     const float ox = float(o.x), oy = float(o.y), oz = float(o.z);
     const float dx = float(d.x), dy = float(d.y), dz = float(d.z);
     const float Tmax = 1.75f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + smax;
-    uint32_t mlo = 0, mhi = 0;
-    float near_t = __builtin_inff();
+    unsigned long long mask = 0;
+    uint32_t near_key = 0xFFFFFFFFu;
     near_rec = -1;
     // only the records named by rec_mask (wave-uniform) are visited
     uint32_t todo = uint32_t(__builtin_amdgcn_readfirstlane(int(rec_mask)));
@@ -215,10 +218,24 @@ __device__ __forceinline__ unsigned long long prefilter_mask(const float *__rest
         const int r = __builtin_ctz(todo);
         todo &= todo - 1u;
         const_float *P = PQc + r * PQ_STRIDE;
+#if PTX_PQ_WIDE_LOADS
+        // the 24 leading floats of the record in two scalar loads (16 + 8 dwords; the record is 128-byte
+        // aligned) instead of one load per run of fields between its unused words: every instruction,
+        // scalar loads included, takes an issue slot of the SIMD
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        typedef float f32x8 __attribute__((ext_vector_type(8)));
+        const f32x16 q0 = *(const f32x16 __attribute__((address_space(4))) *)P;
+        const f32x8 q1 = *(const f32x8 __attribute__((address_space(4))) *)(P + 16);
+        const float nx = q0[0], ny = q0[1], nz = q0[2], pc = q0[3];
+        const float ax = q0[4], ay = q0[5], az = q0[6], bx = q0[8], by = q0[9], bz = q0[10];
+        const float uc = q0[12], uh = q0[13], vc = q0[14], vh = q0[15];
+        const float E = q1[0], E02 = q1[1], k1 = q1[2], Et = q1[4], bthr = q1[6];
+#else
         const float nx = P[0], ny = P[1], nz = P[2], pc = P[3];
         const float ax = P[4], ay = P[5], az = P[6], bx = P[8], by = P[9], bz = P[10];
         const float uc = P[12], uh = P[13], vc = P[14], vh = P[15];
         const float E = P[16], E02 = P[17], k1 = P[18], Et = P[20], bthr = P[22];
+#endif
         const float nd = nx * dx + ny * dy + nz * dz;
         const float no = pc - (nx * ox + ny * oy + nz * oz);
         const float rr = __builtin_amdgcn_rcpf(nd);
@@ -238,17 +255,19 @@ __device__ __forceinline__ unsigned long long prefilter_mask(const float *__rest
         const uint32_t bits = (ka ? 1u : 0u) | (kb ? 2u : 0u);
         if (NEAREST)
         {
+            // nearest candidate so far: one unsigned minimum over keys "bits of the positive lower bound of
+            // its distance, the low five replaced by the record" (no key: all ones).  Which of two records a
+            // few ulps apart comes out only orders the exact tests that follow, never their result.
             const float tlo = t - et;
-            const bool nearer = (ka | kb) & (tlo > 0.0f) & (tlo < near_t);
-            near_t = nearer ? tlo : near_t;
-            near_rec = nearer ? r : near_rec;
+            const uint32_t key = ((ka | kb) & (tlo > 0.0f)) ? ((__float_as_uint(tlo) & ~31u) | uint32_t(r)) : 0xFFFFFFFFu;
+            near_key = key < near_key ? key : near_key;
         }
-        if (r < 16)
-            mlo |= bits << (2 * r);
-        else
-            mhi |= bits << (2 * r - 32);
+        // two bits per record into the 64-bit mask: one 64-bit shift by a wave-uniform amount, no branch on r
+        mask |= (unsigned long long)bits << (2 * r);
     }
-    return ((unsigned long long)mhi << 32) | mlo;
+    if (NEAREST)
+        near_rec = near_key == 0xFFFFFFFFu ? -1 : int(near_key & 31u);
+    return mask;
 }
 
 // A ray that starts on triangle `own` meets the plane of that triangle (and of its coplanar
@@ -288,9 +307,10 @@ __device__ __forceinline__ unsigned long long drop_own_plane(unsigned long long 
 // a triangle whose exact distance could win or tie is never skipped, and hits, distances and ties
 // are those of testing every triangle exactly.
 //
-// Stack entries pack the (truncated, hence still lower-bound) entry distance above the record id
-// (S.id_bits bits): children are ordered by sorting their entries, and an entry whose distance has
-// fallen behind the closest hit is dropped when it is popped, without touching memory.
+// Stack entries keep the bits of the (non-negative) entry distance above the record id (the low
+// S.id_bits bits are the id: the distance is truncated, hence still a lower bound): children are
+// ordered by sorting their entries, and an entry whose distance has fallen behind the closest hit is
+// dropped when it is popped, without touching memory.
 // ---------------------------------------------------------------------------------------------
 template <class R> struct Trav
 {
@@ -457,6 +477,9 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
         const uint32_t qnx = px ? n2.x : n2.y, qfx = px ? n2.y : n2.x; // near / far plane coordinates of the four children
         const uint32_t qny = py ? n2.z : n2.w, qfy = py ? n2.w : n2.z;
         const uint32_t qnz = pz ? n3.x : n3.y, qfz = pz ? n3.y : n3.x;
+        // entry: the bits of the entry distance (non-negative: the sign bit is clear) above the record id --
+        // truncated, hence still a lower bound; one and-or per child
+        const uint32_t key_dist_mask = ~((1u << id_bits) - 1u);
         auto slab = [&](int i, uint32_t child) {
             const float tnx = fmaf(Ax, float((qnx >> (8 * i)) & 255u), Bnx), tfx = fmaf(Ax, float((qfx >> (8 * i)) & 255u), Bfx);
             const float tny = fmaf(Ay, float((qny >> (8 * i)) & 255u), Bny), tfy = fmaf(Ay, float((qfy >> (8 * i)) & 255u), Bfy);
@@ -464,8 +487,10 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
             // tn: a lower bound of the true entry distance, tf: an upper bound of the exit distance
             const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), 0.0f);
             const float tf = fminf(fminf(tfx, tfy), tfz);
-            const bool hit = (tn <= tf) & (tn <= tmaxf) & (child != 0xFFFFFFFFu);
-            return hit ? (((__float_as_uint(tn) >> (id_bits - 1)) << id_bits) | child) : 0xFFFFFFFFu;
+            // (a slot without a child carries the id 0xFFFFFFFF: or-ing it in yields the "no entry" key by
+            // itself, whatever the slab test says -- no compare for it; compares cost two f32 multiplies here)
+            const bool hit = (tn <= tf) & (tn <= tmaxf);
+            return hit ? ((__float_as_uint(tn) & key_dist_mask) | child) : 0xFFFFFFFFu;
         };
         uint32_t k0 = slab(0, n0.w);
         uint32_t k1 = slab(1, n1.w);
@@ -526,7 +551,7 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
             e = uint32_t(*(lds_int_t *)(stk + T.sp * BLOCK));
         else
             e = *(global_u32_t *)(S.spill + (uint32_t(T.sp - S.stack_levels) * uint32_t(S.spill_stride) + (blockIdx.x * BLOCK + threadIdx.x)));
-        if (__uint_as_float((e >> id_bits) << (id_bits - 1)) <= tmaxf)
+        if (__uint_as_float(e & ~id_mask) <= tmaxf)
         {
             T.cur = int(e & id_mask);
             return true;

@@ -44,7 +44,7 @@ typedef unsigned long long u64;
         const unsigned long long t0 = __builtin_readcyclecounter();                                  \
         for (int i = 0; i < iters; i++)                                                              \
             asm volatile(ASM : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), \
-                         "+v"(a7) : "v"(x), "v"(y) : "vcc", "s10", "s11");                                         \
+                         "+v"(a7) : "v"(x), "v"(y) : "vcc", "scc", "s10", "s11", "v60", "v61");                                         \
         const unsigned long long t1 = __builtin_readcyclecounter();                                  \
         if ((threadIdx.x & 63) == 0)                                                                 \
             out[threadIdx.x >> 6] = t1 - t0;                                                         \
@@ -94,6 +94,22 @@ BENCH(k_and_b32, unsigned, unsigned, I64("v_and_b32", "%8, ", ""))
 BENCH(k_lshlrev_b32, unsigned, unsigned, I64("v_lshlrev_b32", "3, ", ""))
 BENCH(k_and_or_b32, unsigned, unsigned, I64("v_and_or_b32", "%8, %9, ", ""))
 BENCH(k_sub_f64_neg, double, double, I64("v_add_f64", "%8, -", ""))
+// mixes: do instructions of different cost classes share the issue port or overlap?  two per line
+BENCH(k_mix_fma_cvt, float, float, I64("v_cvt_f32_i32 %0, %0\nv_fma_f32", "%8, %9, ", ""))
+BENCH(k_mix_fma_max, float, float, I64("v_max_f32 %0, %8, %0\nv_fma_f32", "%8, %9, ", ""))
+BENCH(k_mix_mov_fma64, double, double, I64("v_mov_b32 v60, v61\nv_fma_f64", "%8, %9, ", ""))
+BENCH(k_mix_fma_cmp, float, float, I64("v_cmp_lt_f32 vcc, %8, %0\nv_fma_f32", "%8, %9, ", ""))
+BENCH(k_mix_fma_rcp, float, float, I64("v_rcp_f32 %0, %0\nv_fma_f32", "%8, %9, ", ""))
+BENCH(k_mix_fma_salu, float, float, I64("s_add_u32 s10, s10, 1\nv_fma_f32", "%8, %9, ", ""))
+BENCH(k_mix_max_salu, float, float, I64("s_add_u32 s10, s10, 1\nv_max_f32", "%8, ", ""))
+BENCH(k_cvt_f32_ubyte1, float, unsigned, I64("v_cvt_f32_ubyte1", "%8 ;", ""))
+BENCH(k_or_b32_sdwa_byte1, unsigned, unsigned, I64("v_or_b32_sdwa", "%8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1 ;", ""))
+BENCH(k_perm_b32, unsigned, unsigned, I64("v_perm_b32", "%8, %9, ", ""))
+BENCH(k_bfe_u32, unsigned, unsigned, I64("v_bfe_u32", "%8, 8, 8 ;", ""))
+BENCH(k_min3_f32, float, float, I64("v_min3_f32", "%8, %9, ", ""))
+BENCH(k_max_f32, float, float, I64("v_max_f32", "%8, ", ""))
+BENCH(k_min_u32, unsigned, unsigned, I64("v_min_u32", "%8, ", ""))
+BENCH(k_sub_f32, float, float, I64("v_sub_f32", "%8, ", ""))
 BENCH(k_add_u32, unsigned, unsigned, I64("v_add_u32", "%8, ", ""))
 BENCH(k_xor_b32, unsigned, unsigned, I64("v_xor_b32", "%8, ", ""))
 BENCH(k_lshl_add_u32, unsigned, unsigned, I64("v_lshl_add_u32", "%8, 3, ", ""))
@@ -120,6 +136,8 @@ static Entry entries[] = {
     E(div_scale_f64, 1), E(div_fmas_f64, 1), E(div_fixup_f64, 1), E(trig_preop_f64, 2), E(fract_f64, 1),
     E(cmp_lt_f64, 1), E(cmp_lt_f32, 0), E(cmp_lt_u32, 2), E(cvt_f64_f32, 0), E(cvt_f32_f64, 1), E(mov_b32, 2), E(mov_b64, 1), E(cndmask_b32, 2),
     E(cndmask_e64_sgpr, 2), E(cmp_cndmask_pair, 2), E(add_cndmask_pair, 2), E(readlane, 2), E(readfirstlane, 2), E(writelane, 2), E(mbcnt, 2),
+    E(mix_fma_cvt, 0), E(mix_fma_max, 0), E(mix_mov_fma64, 1), E(mix_fma_cmp, 0), E(mix_fma_rcp, 0), E(mix_fma_salu, 0), E(mix_max_salu, 0),
+    E(cvt_f32_ubyte1, 2), E(or_b32_sdwa_byte1, 2), E(perm_b32, 2), E(bfe_u32, 2), E(min3_f32, 0), E(max_f32, 0), E(min_u32, 2), E(sub_f32, 0),
     E(and_b32, 2), E(lshlrev_b32, 2), E(and_or_b32, 2), E(sub_f64_neg, 1), E(add_u32, 2), E(xor_b32, 2), E(lshl_add_u32, 2), E(add3_u32, 2), E(mul_lo_u32, 2), E(mul_hi_u32, 2), E(mul_u32_u24, 2),
     E(mad_u64_u32, 2), E(lshlrev_b64, 2), E(lshrrev_b64, 2), E(lshl_add_u64, 3), E(bpermute, 2)};
 
