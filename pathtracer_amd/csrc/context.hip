@@ -119,6 +119,7 @@ struct StateNeeds
 // not use the array's name as an address (it is a host-side stand-in): the device address comes
 // from hipGetSymbolAddress, once per device, in Context::Context.
 constexpr size_t STATIC_STATE_BYTES = size_t(256) << 20;
+static_assert(WF_MAX_LIGHTS >= RING_MAX_TESTS && WF_QUEUE_HEADER_WORDS * 4 <= 256, "the test queue's header holds a list length per light");
 static __device__ __align__(256) unsigned char scratch[STATIC_STATE_BYTES];
 
 // per-precision device tables + per-batch path state
@@ -1072,7 +1073,7 @@ static void launch_wavefront(const TracePlan<R> &plan, const DScene<R> &S, const
             // shading sends the visibility tests of the bounce to the test queue, an any-hit launch answers
             // them, the gather fills in the light-sampling half of the bounce's records
             const WfQueue<R> &tq = im.wft;
-            HIP_CHECK(hipMemsetAsync(tq.count, 0, 8, s));
+            HIP_CHECK(hipMemsetAsync(tq.count, 0, WF_QUEUE_HEADER_WORDS * sizeof(uint32_t), s)); // pool and the lengths of the per-light lists
             if (b == 0)
                 hipLaunchKernelGGL((k_wf_shade_fast<R, true>), shade_grid, dim3(WF_SHADE_BLOCK), 0, s, S, B, in, out, tq, im.wfs, b);
             else
@@ -1090,7 +1091,7 @@ static void launch_wavefront(const TracePlan<R> &plan, const DScene<R> &S, const
         {
             // the reference's estimator with square lights: the same three steps
             const WfQueue<R> &tq = im.wft;
-            HIP_CHECK(hipMemsetAsync(tq.count, 0, 8, s));
+            HIP_CHECK(hipMemsetAsync(tq.count, 0, WF_QUEUE_HEADER_WORDS * sizeof(uint32_t), s)); // pool and the lengths of the per-light lists
             if (b == 0)
                 hipLaunchKernelGGL((k_wf_shade<R, true, true>), shade_grid, dim3(WF_SHADE_BLOCK), 0, s, S, B, in, out, tq, im.wfs, b);
             else

@@ -33,6 +33,13 @@ template <class R> struct WfQueue
     uint32_t *pool;    // next ray no lane has taken yet (k_wf_traverse)
     int64_t cap;
 };
+// The queue of visibility tests keeps a test in the slot light x segments + segment (where the gather
+// looks for its answer) and names the slots that hold one in a dense list per light: list l is
+// pid[l * segments ...], its length count[WF_TEST_COUNTS + l], the segment count count[WF_TEST_SEGS].
+// The any-hit launch walks the lists one after the other, so no lane ever takes an empty slot and
+// neighbouring lanes test neighbouring segments against the same light.
+constexpr int WF_MAX_LIGHTS = 12, WF_TEST_SEGS = 2, WF_TEST_COUNTS = 4;
+constexpr int WF_QUEUE_HEADER_WORDS = WF_TEST_COUNTS + WF_MAX_LIGHTS;
 
 // a wave runs a triangle step (exact test in R) instead of a node step (four f32 slab tests) when
 // lanes at triangles x A > lanes at nodes x B
@@ -51,10 +58,20 @@ constexpr int WF_CHUNK = PTX_WF_CHUNK; // queue entries a wave of the traversal 
 template <class R, int ANY> __device__ __forceinline__ void wf_traverse_body(const DScene<R> &S, const WfQueue<R> &Q, int refill, unsigned long long *wave_stats)
 {
     int *stk = dyn_stack + threadIdx.x;
+    __shared__ uint32_t list_begin[ANY ? WF_MAX_LIGHTS + 1 : 1]; // ANY: where each light's list starts in the walk over all of them
+    if constexpr (ANY)
+        if (threadIdx.x == 0)
+        {
+            uint32_t a = 0;
+            for (int l = 0; l < S.n_lights; l++)
+                list_begin[l] = a, a += Q.count[WF_TEST_COUNTS + l];
+            list_begin[S.n_lights] = a;
+        }
     stage_hot_nodes(S);
     __syncthreads(); // the only barrier
     const int lane = lane_id(), g = global_wave();
-    const uint32_t n = *Q.count;
+    const uint32_t n = ANY ? list_begin[S.n_lights] : *Q.count;
+    const size_t n_seg = ANY ? size_t(Q.count[WF_TEST_SEGS]) : size_t(0);
     bool busy = false, drained = false;
     uint32_t idx = 0;
     uint32_t next = 0, end = 0; // the wave's current range of queue entries (wave-uniform)
@@ -80,9 +97,17 @@ template <class R, int ANY> __device__ __forceinline__ void wf_traverse_body(con
                 next = base < n ? base : n;
                 end = n - next < uint32_t(WF_CHUNK) ? n : next + uint32_t(WF_CHUNK);
             }
-            const uint32_t i = next + rank_in(idle);
+            uint32_t i = next + rank_in(idle);
             if (!busy && i < end)
             {
+                if constexpr (ANY)
+                {
+                    // entry i of the lists laid end to end -> the slot it names
+                    int l = 0;
+                    while (l + 1 < S.n_lights && i >= list_begin[l + 1])
+                        l++;
+                    i = Q.pid[size_t(l) * n_seg + (i - list_begin[l])];
+                }
                 o = {Q.o[i], Q.o[cap + i], Q.o[2 * cap + i]};
                 d = {Q.d[i], Q.d[cap + i], Q.d[2 * cap + i]};
                 idx = i, busy = true;
@@ -90,7 +115,7 @@ template <class R, int ANY> __device__ __forceinline__ void wf_traverse_body(con
                 {
                     const R len = Q.t[i];
                     trav_init(S, T, o, d, len);
-                    busy = len >= R(0); // a slot without a test
+                    busy = len >= R(0);
                 }
                 else
                     trav_init(S, T, o, d);
@@ -103,7 +128,7 @@ template <class R, int ANY> __device__ __forceinline__ void wf_traverse_body(con
         {
             if (drained)
                 break; // nothing left to take and every lane idle
-            continue;  // the slots just taken held no test: take the next ones (ends: the range only moves forward)
+            continue;  // nothing taken: take the next ones (ends: the range only moves forward)
         }
         // ---- traversal steps until enough lanes are idle again ----------------------------------
         for (;;)
@@ -231,6 +256,45 @@ template <class R> __global__ void k_wf_counts(WfQueue<R> A, uint32_t count_a, W
 #define PTX_WF_SHADE_WAVES 6 // waves per SIMD k_wf_shade is compiled for
 #endif
 constexpr int WF_SHADE_BLOCK = PTX_WF_SHADE_BLOCK;
+// Appends the test slots of a workgroup's segments to the per-light lists of the test queue: one
+// atomic add per light and workgroup (the counts of its waves are summed in LDS first), the slots of
+// a wave side by side.  tmask: the lights this thread's segment has a test against (bit l: slot
+// t0 + l * tstep).  Every thread of the workgroup calls it.
+template <class R>
+__device__ __forceinline__ void wf_list_tests(const WfQueue<R> &tests, uint32_t tmask, int n_lights, size_t t0, size_t tstep)
+{
+    __shared__ uint32_t wave_cnt[WF_SHADE_BLOCK / 64][WF_MAX_LIGHTS]; // tests per wave and light, then the wave's offset in the workgroup's range
+    __shared__ uint32_t list_base[WF_MAX_LIGHTS];
+    const int lane = lane_id(), wave = int(threadIdx.x >> 6);
+    for (int l = 0; l < n_lights; l++)
+    {
+        const unsigned long long b = __ballot((tmask >> l) & 1u);
+        if (lane == 0)
+            wave_cnt[wave][l] = uint32_t(__popcll(b));
+    }
+    __syncthreads();
+    if (int(threadIdx.x) < n_lights)
+    {
+        const int l = int(threadIdx.x);
+        uint32_t total = 0;
+        for (int w = 0; w < WF_SHADE_BLOCK / 64; w++)
+        {
+            const uint32_t c = wave_cnt[w][l];
+            wave_cnt[w][l] = total;
+            total += c;
+        }
+        list_base[l] = total ? atomicAdd(tests.count + WF_TEST_COUNTS + l, total) : 0u;
+    }
+    __syncthreads();
+    for (int l = 0; l < n_lights; l++)
+    {
+        const bool has = (tmask >> l) & 1u;
+        const unsigned long long b = __ballot(has);
+        if (has)
+            tests.pid[size_t(l) * tstep + list_base[l] + wave_cnt[wave][l] + rank_in(b)] = uint32_t(t0 + size_t(l) * tstep);
+    }
+}
+
 // CAM: the launch of bounce 0 -- one thread per path of the batch, the hit of its pixel's camera ray.
 // SQ: the scene has square lights (at most 12 lights in all), whose samples need the reference's
 // visibility test: every light with a term gets its slot light x segments + segment of the test
@@ -255,10 +319,10 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, PTX_WF_SHADE_WAVES)
     const size_t N = size_t(W.N);
     bool cont = false;
     V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
-    uint32_t pid = 0, n_rec = 0, n_test = 0;
+    uint32_t pid = 0, n_rec = 0, n_test = 0, tmask = 0;
     const size_t tcap = size_t(tests.cap), t0 = size_t(i), tstep = size_t(n); // this segment's test slots: t0 + light * tstep
     if (SQ && i == 0u)
-        *tests.count = n * uint32_t(S.n_lights);
+        tests.count[WF_TEST_SEGS] = n;
     if (mine)
     {
         if constexpr (SQ)
@@ -340,7 +404,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, PTX_WF_SHADE_WAVES)
                         tests.o[r] = ro.x, tests.o[tcap + r] = ro.y, tests.o[2 * tcap + r] = ro.z;
                         tests.d[r] = dir.x, tests.d[tcap + r] = dir.y, tests.d[2 * tcap + r] = dir.z;
                         tests.t[r] = dist;
-                        n_test++;
+                        n_test++, tmask |= 1u << l;
                     }
                     else
                         tests.t[r] = R(-2); // a sphere light: its term counts without a test
@@ -418,6 +482,8 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, PTX_WF_SHADE_WAVES)
         out.d[r] = wi.x, out.d[cap + r] = wi.y, out.d[2 * cap + r] = wi.z;
         out.pid[r] = pid;
     }
+    if constexpr (SQ)
+        wf_list_tests(tests, tmask, S.n_lights, t0, tstep);
 }
 
 // The physically based estimator (device_math.hpp, "fast"; the FAST branches of trace_body and
@@ -449,10 +515,10 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, PTX_WF_SHADE_FAST_WAVES)
     const size_t N = size_t(W.N);
     bool cont = false;
     V3<R> p = {R(0), R(0), R(0)}, wi = {R(0), R(0), R(0)};
-    uint32_t pid = 0, n_rec = 0, n_test = 0;
+    uint32_t pid = 0, n_rec = 0, n_test = 0, tmask = 0;
     const size_t tcap = size_t(tests.cap), t0 = size_t(i), tstep = size_t(n); // this segment's test slots: t0 + light * tstep
     if (i == 0u)
-        *tests.count = n * uint32_t(S.n_lights);
+        tests.count[WF_TEST_SEGS] = n;
     if (mine)
     {
         for (int l = 0; l < S.n_lights; l++)
@@ -567,7 +633,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, PTX_WF_SHADE_FAST_WAVES)
                     tests.d[r] = dir.x, tests.d[tcap + r] = dir.y, tests.d[2 * tcap + r] = dir.z;
                     tests.t[r] = dist;
                     W.term[r] = thr.x * L[1] * f.x * w, W.term[tcap + r] = thr.y * L[2] * f.y * w, W.term[2 * tcap + r] = thr.z * L[3] * f.z * w;
-                    n_test++;
+                    n_test++, tmask |= 1u << l;
                 }
                 if (go_on)
                 {
@@ -657,6 +723,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, PTX_WF_SHADE_FAST_WAVES)
         out.d[r] = wi.x, out.d[cap + r] = wi.y, out.d[2 * cap + r] = wi.z;
         out.pid[r] = pid;
     }
+    wf_list_tests(tests, tmask, S.n_lights, t0, tstep);
 }
 
 // After the any-hit launch: the light-sampling half of every record of the bounce = the terms of the

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 SCENE=${2:-cbox}
 shift || true
 shift || true
-CMD="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fast-estimator $*"
+CMD="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fast-estimator --no-scenes $*"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $CMD > $O/bench_kt.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/sq -o sq -- $CMD > $O/bench_sq.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch -- $CMD > $O/bench_fetch.log 2>&1
