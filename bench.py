@@ -355,6 +355,20 @@ def main():
                     "path_lane_fraction": round(ps["segments"] / (64.0 * max(ps["wave_iterations"], 1)), 4),
                     "active_lanes_per_valu_inst": cal.get("active_lanes_per_valu_inst"),
                     "source": cal.get("source")}
+        # the committed issue account of the kernel this run launched (tools/issue_cycles.py: hardware
+        # instruction-class counters priced with the opcode costs measured on this GPU), quoted, not re-measured
+        if valu is not None:
+            acct_path = os.path.join(ROOT, "profiles", "r03_%s_issue_cycles.json" % scene_name)
+            if os.path.exists(acct_path):
+                acct = json.load(open(acct_path)).get("kernels", {})
+                first = ran.split(" + ")[0]
+                entry = next((v for k, v in acct.items() if k.replace("ptx::", "") == first), None)
+                if entry:
+                    valu["issue_account"] = {k: entry.get(k) for k in ("avg_launch_ms", "valu_slot_frac", "all_slot_frac", "f64_unit_frac",
+                                                                      "issue_cycle_frac", "hw_valu_busy_frac", "salu_per_valu",
+                                                                      "wait_any_share_of_wave_cycles")}
+                    valu["issue_account"]["kernel"] = first
+                    valu["issue_account"]["source"] = "profiles/r03_%s_issue_cycles.json" % scene_name
         kernel_ms = {k: round(v, 3) for k, v in ms.items()}
         kernel_ms["other"] = round(ps["ms_other"], 3)
 

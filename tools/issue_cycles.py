@@ -15,6 +15,21 @@ shifts and logic, cross-lane reads -- is priced by the kernel's STATIC mix of ex
 assembly at the mean of move, select and compare.  The hardware's own busy measure is printed beside
 it: SQ_ACTIVE_INST_VALU (quad-cycles a wave spent in VALU instructions) x 4 / available.
 
+Beside that weighted sum stand two ISSUE-SLOT figures.  In the micro-benchmark's mixed streams an f32
+fma alternating with a compare, a conversion, a max or a scalar add of the SAME wave takes 4.28 cycles
+per pair whichever the partner (although compare, conversion and max cost 4.1 back to back): a wave's
+instruction takes a slot of about 2.14 cycles, and a 4-cycle class keeps only its own unit busy
+beyond the slot.
+    valu_slot_frac  = VALU instructions x slot / available: what the vector issue port is busy with
+                      if every vector instruction overlaps the tail of the one before (lower bound)
+    all_slot_frac   = (VALU + SALU + LDS + VMEM + SMEM) x slot / available: the same if scalar and
+                      memory instructions of OTHER waves took slots of the vector port too.  They do
+                      not always: the f32 traversal kernel (8 waves per SIMD) comes out above 1, so
+                      this is an upper bound, and the truth lies between the two
+    f64_unit_frac   = f64 arithmetic x its back-to-back cost / available (the double-precision unit)
+issue_cycle_frac above prices every VALU instruction at its back-to-back cost, as if no two classes
+overlapped.
+
     issue_cycles.py dump <kt.db> <a.db> <b.db> <c.db>                 (GPU box) -> raw counters, JSON
     issue_cycles.py combine <tag> <valu_issue.json> <bench.json> <raw.json> [--isa context.s]
                                                                       -> profiles/<tag>_issue_cycles.json"""
@@ -148,6 +163,10 @@ def combine(tag, cost_json, bench_json, raw_json, isa):
         cycles = {n: classes[n] * price[n] for n in price}
         cycles["unclassified (moves, selects, compares, shifts and logic, cross-lane)"] = rest * rest_price
         issue = sum(cycles.values())
+        slot = 0.5 * c.get("mix_fma_max", 2.0 * c["fma_f32"])
+        others = {n: per("SQ_INSTS_" + n) for n in ("SALU", "LDS", "VMEM", "SMEM")}
+        all_insts = valu + sum(others.values())
+        f64_unit = sum(cycles[n] for n in price if n.endswith("_F64"))
         act = per("SQ_ACTIVE_INST_VALU")
         lanes = per("SQ_THREAD_CYCLES_VALU") / act / 64.0 if act else None
         out["kernels"][k] = {
@@ -157,6 +176,9 @@ def combine(tag, cost_json, bench_json, raw_json, isa):
             "unclassified_static_opcodes": rest_static, "static_valu_opcodes": valu_static,
             "issue_cycles_per_launch": round(issue), "available_simd_cycles_per_launch": round(avail),
             "issue_cycle_frac": round(issue / avail, 4),
+            "issue_slot_cycles": round(slot, 3), "instructions_per_launch": {"VALU": round(valu), **{n: round(v) for n, v in others.items()}},
+            "valu_slot_frac": round(valu * slot / avail, 4), "all_slot_frac": round(all_insts * slot / avail, 4),
+            "f64_unit_frac": round(f64_unit / avail, 4),
             "hw_valu_busy_frac": round(4.0 * act / avail, 4) if act else None,
             "issue_cycle_share_by_class": {n: round(v / issue, 4) for n, v in sorted(cycles.items(), key=lambda kv: -kv[1])},
             "mean_cycles_per_valu_instruction": round(issue / valu, 3) if valu else None,
@@ -180,8 +202,8 @@ def main():
         isa = sys.argv[sys.argv.index("--isa") + 1] if "--isa" in sys.argv else None
         out = combine(tag, cost_json, bench_json, raw_json, isa)
         for k, v in out["kernels"].items():
-            print("%-46s %8.3f ms  issue %.3f  hw busy %s  lanes %s  wait %s  cycles/inst %.2f" % (
-                k.replace("ptx::", ""), v["avg_launch_ms"], v["issue_cycle_frac"], v["hw_valu_busy_frac"],
+            print("%-46s %8.3f ms  slots VALU %.3f .. all %.3f  f64 unit %.3f  weighted VALU %.3f  hw busy %s  lanes %s  wait %s  cycles/inst %.2f" % (
+                k.replace("ptx::", ""), v["avg_launch_ms"], v["valu_slot_frac"], v["all_slot_frac"], v["f64_unit_frac"], v["issue_cycle_frac"], v["hw_valu_busy_frac"],
                 v["active_lanes_per_valu_instruction"], v["wait_any_share_of_wave_cycles"], v["mean_cycles_per_valu_instruction"]))
 
 

@@ -12,7 +12,7 @@ O=$R/gpurun_out/issue_$TAG
 mkdir -p $O
 timeout -k 5 120 $R/tools/microbench/valu_issue 2000 > $O/valu_issue.json
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fast-estimator $*"
+CMD="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fast-estimator --no-scenes $*"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $CMD > $O/bench_kt.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT -d $O/a -o a -- $CMD > $O/bench_a.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM -d $O/b -o b -- $CMD > $O/bench_b.log 2>&1
