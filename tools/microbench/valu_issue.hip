@@ -102,6 +102,12 @@ BENCH(k_mix_fma_cmp, float, float, I64("v_cmp_lt_f32 vcc, %8, %0\nv_fma_f32", "%
 BENCH(k_mix_fma_rcp, float, float, I64("v_rcp_f32 %0, %0\nv_fma_f32", "%8, %9, ", ""))
 BENCH(k_mix_fma_salu, float, float, I64("s_add_u32 s10, s10, 1\nv_fma_f32", "%8, %9, ", ""))
 BENCH(k_mix_max_salu, float, float, I64("s_add_u32 s10, s10, 1\nv_max_f32", "%8, ", ""))
+// packed f32: two operations per lane and instruction on 64-bit register pairs
+BENCH(k_pk_fma_f32, double, double, I64("v_pk_fma_f32", "%8, %9, ", ""))
+BENCH(k_pk_mul_f32, double, double, I64("v_pk_mul_f32", "%8, ", ""))
+BENCH(k_pk_add_f32, double, double, I64("v_pk_add_f32", "%8, ", ""))
+BENCH(k_mix_mov_pkfma, double, double, I64("v_mov_b32 v60, v61\nv_pk_fma_f32", "%8, %9, ", ""))
+BENCH(k_mix_cmp_pkfma, double, double, I64("v_cmp_lt_f64 vcc, %8, %0\nv_pk_fma_f32", "%8, %9, ", ""))
 BENCH(k_cvt_f32_ubyte1, float, unsigned, I64("v_cvt_f32_ubyte1", "%8 ;", ""))
 BENCH(k_or_b32_sdwa_byte1, unsigned, unsigned, I64("v_or_b32_sdwa", "%8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1 ;", ""))
 BENCH(k_perm_b32, unsigned, unsigned, I64("v_perm_b32", "%8, %9, ", ""))
@@ -137,6 +143,7 @@ static Entry entries[] = {
     E(cmp_lt_f64, 1), E(cmp_lt_f32, 0), E(cmp_lt_u32, 2), E(cvt_f64_f32, 0), E(cvt_f32_f64, 1), E(mov_b32, 2), E(mov_b64, 1), E(cndmask_b32, 2),
     E(cndmask_e64_sgpr, 2), E(cmp_cndmask_pair, 2), E(add_cndmask_pair, 2), E(readlane, 2), E(readfirstlane, 2), E(writelane, 2), E(mbcnt, 2),
     E(mix_fma_cvt, 0), E(mix_fma_max, 0), E(mix_mov_fma64, 1), E(mix_fma_cmp, 0), E(mix_fma_rcp, 0), E(mix_fma_salu, 0), E(mix_max_salu, 0),
+    E(pk_fma_f32, 1), E(pk_mul_f32, 1), E(pk_add_f32, 1), E(mix_mov_pkfma, 1), E(mix_cmp_pkfma, 1),
     E(cvt_f32_ubyte1, 2), E(or_b32_sdwa_byte1, 2), E(perm_b32, 2), E(bfe_u32, 2), E(min3_f32, 0), E(max_f32, 0), E(min_u32, 2), E(sub_f32, 0),
     E(and_b32, 2), E(lshlrev_b32, 2), E(and_or_b32, 2), E(sub_f64_neg, 1), E(add_u32, 2), E(xor_b32, 2), E(lshl_add_u32, 2), E(add3_u32, 2), E(mul_lo_u32, 2), E(mul_hi_u32, 2), E(mul_u32_u24, 2),
     E(mad_u64_u32, 2), E(lshlrev_b64, 2), E(lshrrev_b64, 2), E(lshl_add_u64, 3), E(bpermute, 2)};
