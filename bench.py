@@ -518,10 +518,12 @@ def cpu_baseline_and_checks(ctx, args, W, H):
         from oracle import parity
         r = parity.check_f64_image(gimg, oimg, ctx, O, range(spp), seed=13, max_pixels=24)
         checks.update({"f64_pixels_beyond_1e-9": r["beyond"], "put_to_the_proof": r["put_to_the_proof"],
-                       "proven_ties": r["proven_ties"], "unmatched_samples": len(r["unmatched"]),
+                       "proven_ties": r["proven_ties"], "amplified_roundings": r["amplified"],
+                       "largest_amplification": max(r["amplifications"]) if r["amplifications"] else None,
+                       "unmatched_samples": len(r["unmatched"]),
                        "largest_difference": r["largest_difference"], "rmse_bar": 1e-4,
                        "pass": bool((ids == oids).all() and not r["unmatched"] and r["no_sample_differs"] == 0
-                                    and r["proven_ties"] == r["put_to_the_proof"] and rmse < 1e-4)})
+                                    and r["explained"] == r["put_to_the_proof"] and rmse < 1e-4)})
     else:
         # f32: statistical bar  max(2 x the oracle's own two-seed noise floor, 1e-3); the floor costs a
         # second CPU render and is only measured at low spp -- without it the bar is the 1e-3 it can never go below

@@ -69,6 +69,8 @@ def lib():
         L.orc_trace_sample_ties.restype = C.c_int32
         L.orc_trace_sample_ties.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_double,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_trace_sample_perturbed.restype = C.c_int32
+        L.orc_trace_sample_perturbed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
         L.orc_vistest.restype = C.c_int
         L.orc_square_light_sample.restype = C.c_double
         L.orc_square_light_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double,
@@ -192,6 +194,22 @@ class Oracle:
         n = lib().orc_trace_sample_ties(C.byref(self.c), int(x), int(y), int(sample), int(mask), float(gap),
                                         _p(rgb), _p(faces), _p(margins), C.byref(nt))
         return rgb, faces[:n].copy(), margins[:n].copy(), int(nt.value)
+
+    def amplification(self, x, y, sample, eps=1e-9):
+        """How strongly the sample's value reacts to an error of one of its own sampled directions:
+        max over the bounces b of |value(direction of bounce b turned by eps) - value| / eps (reference's
+        estimator only; None otherwise).  1..10 on flat, diffuse geometry; curved, smoothly shaded
+        surfaces multiply a direction error at every further bounce."""
+        base = np.zeros(3)
+        n = lib().orc_trace_sample_perturbed(C.byref(self.c), int(x), int(y), int(sample), -1, 0.0, _p(base))
+        if n < 0:
+            return None
+        worst = 0.0
+        for b in range(max(n, 1)):
+            rgb = np.zeros(3)
+            lib().orc_trace_sample_perturbed(C.byref(self.c), int(x), int(y), int(sample), b, float(eps), _p(rgb))
+            worst = max(worst, float(np.abs(rgb - base).max()) / eps)
+        return worst
 
     def tie_alternatives(self, x, y, sample, gap=1e-10, max_ties=6):
         """Every value the sample can take when the ties on its path fall either way: a list of

@@ -1010,7 +1010,34 @@ typedef struct
     int32_t face[ORC_MAX_DEPTH];
     double margin[ORC_MAX_DEPTH];
     orc_tie tie; /* which way the ties of this path fall (mask 0: the reference's own rule) */
+    /* sensitivity probe: the direction sampled at bounce perturb_bounce (-1: none) is turned by
+     * about perturb_eps radians before the path goes on */
+    int32_t perturb_bounce;
+    double perturb_eps;
 } orc_probe;
+
+/* turns the unit vector w by about eps radians (towards a fixed, generally non-parallel direction made
+ * of its own components) and renormalises */
+static void perturb_direction(double *w, double eps)
+{
+    double e[3] = {w[1], w[2], -w[0]};
+    double k = dot3(e, w);
+    for (int i = 0; i < 3; i++)
+        e[i] -= k * w[i]; /* the part of e orthogonal to w */
+    double en = norm3(e);
+    if (!(en > 1e-3))
+    {
+        e[0] = w[2], e[1] = -w[0], e[2] = w[1];
+        k = dot3(e, w);
+        for (int i = 0; i < 3; i++)
+            e[i] -= k * w[i];
+        en = norm3(e);
+    }
+    double t[3];
+    for (int i = 0; i < 3; i++)
+        t[i] = w[i] + eps * e[i] / en;
+    normalize3(t, w);
+}
 
 /* one iteration of the sample loop (cPathTracer.cpp:578-693): final = the sample's radiance after
  * the back-to-front combine, before the division by the sample count */
@@ -1073,6 +1100,8 @@ static void trace_sample(const orc_scene *sc, const double *o0, const double *d0
             xi[0] = orc_rng(sc->seed, pixel, sample, (uint32_t)bounce, 4 * sc->n_lights + 0);
             xi[1] = orc_rng(sc->seed, pixel, sample, (uint32_t)bounce, 4 * sc->n_lights + 1);
             orc_bxdf_sample(mat_, n, wo, xi, wi, C[len]);
+            if (probe && probe->perturb_bounce == bounce)
+                perturb_direction(wi, probe->perturb_eps);
             len++;
             for (int i = 0; i < 3; i++)
                 o[i] = p[i], d[i] = wi[i];
@@ -1477,6 +1506,7 @@ int32_t orc_trace_sample_ties(const orc_scene *sc, int x, int y, int sample, uin
     double mat[16], o0[3], d0[3];
     orc_probe pr;
     pr.tie.mask = tie_mask, pr.tie.n = 0, pr.tie.gap = gap;
+    pr.perturb_bounce = -1, pr.perturb_eps = 0;
     orc_camera_matrix(sc, mat);
     primary_ray(sc, mat, x, y, o0, d0);
     if (sc->estimator == 1)
@@ -1492,6 +1522,25 @@ int32_t orc_trace_sample_ties(const orc_scene *sc, int x, int y, int sample, uin
     }
     if (n_ties)
         *n_ties = pr.tie.n;
+    return pr.n;
+}
+
+/* Sensitivity of one sample to its own roundings (tests only; the reference's estimator): the sample
+ * traced with the direction it draws at `bounce` turned by about eps radians.  The difference to the
+ * unperturbed value, divided by eps, says how strongly the rest of the path amplifies an error of that
+ * direction -- curved, smoothly shaded geometry multiplies it at every further bounce.  Returns the
+ * number of bounces traced (the perturbation has no effect when the path ends before `bounce`). */
+int32_t orc_trace_sample_perturbed(const orc_scene *sc, int x, int y, int sample, int bounce, double eps, double *rgb)
+{
+    double mat[16], o0[3], d0[3];
+    orc_probe pr;
+    pr.tie.mask = 0u, pr.tie.n = 0, pr.tie.gap = -1.0;
+    pr.perturb_bounce = bounce, pr.perturb_eps = eps;
+    orc_camera_matrix(sc, mat);
+    primary_ray(sc, mat, x, y, o0, d0);
+    if (sc->estimator == 1)
+        return -1;
+    trace_sample(sc, o0, d0, (uint32_t)(y * sc->width + x), (uint32_t)sample, rgb, NULL, &pr);
     return pr.n;
 }
 

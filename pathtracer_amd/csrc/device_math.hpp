@@ -177,8 +177,14 @@ template <class R> __device__ __forceinline__ V3<R> refract(V3<R> n, V3<R> in, R
     return ni * c - n * s;
 }
 
-// 3x3 inverse times vector, cofactors of column 0 / determinant along column 0 (row-major m)
-template <class R> __device__ __forceinline__ V3<R> solve3(const R *m, V3<R> p)
+// 3x3 inverse times vector, cofactors of column 0 / determinant along column 0 (row-major m).
+// The matrix holds absolute vertex positions (cGeoUtil.cpp:174-231), so a triangle whose plane passes
+// near the origin makes the cofactors cancel.  In double precision the solve is therefore NOT
+// contracted and summed in the order of the other short sums: a fused multiply-add moves the weights
+// of such a triangle by 1e-9 of their size, enough to push a pixel past the f64 parity bar (12 of 8.3
+// million at 3840 x 2160 on room.obj).  Single precision keeps its fused form: there the unfused
+// cofactors can cancel to a determinant of exactly zero, and the weights become NaN.
+template <class R> __device__ __forceinline__ V3<R> solve3_fused(const R *m, V3<R> p)
 {
 #pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
     R c00 = m[4] * m[8] - m[5] * m[7];
@@ -195,6 +201,25 @@ template <class R> __device__ __forceinline__ V3<R> solve3(const R *m, V3<R> p)
     R i8 = (m[0] * m[4] - m[1] * m[3]) * id;
     return {i0 * p.x + i1 * p.y + i2 * p.z, i3 * p.x + i4 * p.y + i5 * p.z, i6 * p.x + i7 * p.y + i8 * p.z};
 }
+template <class R> __device__ __forceinline__ V3<R> solve3_exact(const R *m, V3<R> p)
+{
+#pragma clang fp contract(off)
+    R c00 = m[4] * m[8] - m[5] * m[7];
+    R c10 = m[7] * m[2] - m[8] * m[1];
+    R c20 = m[1] * m[5] - m[2] * m[4];
+    R det = PTX_SUM3(c00 * m[0], c10 * m[3], c20 * m[6]);
+    R id = R(1) / det;
+    R i0 = c00 * id, i1 = c10 * id, i2 = c20 * id;
+    R i3 = (m[5] * m[6] - m[3] * m[8]) * id;
+    R i4 = (m[8] * m[0] - m[6] * m[2]) * id;
+    R i5 = (m[2] * m[3] - m[0] * m[5]) * id;
+    R i6 = (m[3] * m[7] - m[4] * m[6]) * id;
+    R i7 = (m[6] * m[1] - m[7] * m[0]) * id;
+    R i8 = (m[0] * m[4] - m[1] * m[3]) * id;
+    return {PTX_SUM3(i0 * p.x, i1 * p.y, i2 * p.z), PTX_SUM3(i3 * p.x, i4 * p.y, i5 * p.z), PTX_SUM3(i6 * p.x, i7 * p.y, i8 * p.z)};
+}
+__device__ __forceinline__ V3<double> solve3(const double *m, V3<double> p) { return solve3_exact(m, p); }
+__device__ __forceinline__ V3<float> solve3(const float *m, V3<float> p) { return solve3_fused(m, p); }
 
 // barycentric weights of p w.r.t. (a,b,c): [a b c]^-1 p with all-zero rows regularised.  The
 // reference normalises the weight vector; the caller normalises the interpolated normal anyway, so

@@ -52,8 +52,9 @@ def pytest_terminal_summary(terminalreporter):
     rows = getattr(mod, "OUTLIERS", None) if mod else None
     if rows:
         total = sum(r[1] for r in rows)
-        terminalreporter.write_line("f64 parity: %d image comparisons, %d pixels beyond 1e-9 in all (every one matched to a named tie alternative):"
-                                    % (len(rows), total))
-        for name, bad, n, proven in rows:
+        terminalreporter.write_line("f64 parity: %d image comparisons, %d pixels beyond 1e-9 in all (every one matched to a named tie "
+                                    "alternative, or -- %d of them -- to the amplification the oracle measures on the path):"
+                                    % (len(rows), total, sum(r[4] for r in rows)))
+        for name, bad, n, proven, amplified in rows:
             if bad:
-                terminalreporter.write_line("  %s: %d of %d pixels, %d proven" % (name, bad, n, proven))
+                terminalreporter.write_line("  %s: %d of %d pixels, %d proven ties, %d amplified roundings" % (name, bad, n, proven, amplified))

@@ -28,13 +28,15 @@ def assert_f64_parity(img, oimg, st=None, ost=None, depth=15, ctx=None, O=None, 
     pixel, each of its samples is rendered alone on the GPU (through the C ABI) and re-traced by the
     oracle; a sample whose two values differ must equal, to F64_TOL, the oracle's value with the
     closest-hit ties on its path (winner and runner-up within 1e-10) falling another, named way.
-    That a tie exists on the path is not enough.  Without ctx and O no exception is allowed at
-    all.  origin: (row, column) of img[0, 0] in the frame ctx renders.  Returns the number of
+    That a tie exists on the path is not enough.  A sample without ties may instead be an amplified
+    rounding: its difference within 1024 ulps times the factor by which the oracle measures the path to
+    multiply an error of its directions (counted and reported apart).  Without ctx and O no exception
+    is allowed at all.  origin: (row, column) of img[0, 0] in the frame ctx renders.  Returns the number of
     differing pixels."""
     img, oimg = np.asarray(img), np.asarray(oimg)
     bad, diff = parity.outliers(img, oimg)
     n_bad = len(bad)
-    proven = 0
+    proven = amplified = 0
     if n_bad:
         assert ctx is not None and O is not None, "%d of %d pixels differ by more than %g" % (n_bad, diff.size, F64_TOL)
         n_spp = int(spp if spp is not None else O.c.spp)
@@ -45,8 +47,9 @@ def assert_f64_parity(img, oimg, st=None, ost=None, depth=15, ctx=None, O=None, 
         assert not r["unmatched"], "samples that differ from the oracle and equal no tie alternative of their path: %s" % (r["unmatched"][:3],)
         assert r["no_sample_differs"] == 0, "%d pixels differ although none of their samples does" % r["no_sample_differs"]
         proven = r["proven_ties"]
-        assert proven == n_bad
-    OUTLIERS.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], n_bad, int(diff.size), proven))
+        assert proven + r["amplified"] == n_bad
+        amplified = r["amplified"]
+    OUTLIERS.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], n_bad, int(diff.size), proven, amplified))
     assert oracle.rmse_rel(img, oimg) < 1e-4
     if st is not None:
         assert st["paths"] == ost["paths"]

@@ -352,3 +352,32 @@ def test_sum_order_variants_agree_on_what_is_compared_bit_for_bit(root):
         assert np.nanmax(np.abs(out[v][1] - out[0][1])) < 1e-13
         assert (out[v][1] != out[0][1]).any()                       # they ARE different arithmetic
         assert np.abs(out[v][2] - out[0][2]).max() < 1e-9 or (np.abs(out[v][2] - out[0][2]).max(axis=-1) > 1e-9).sum() <= 2
+
+
+def test_amplification_names_the_paths_that_multiply_their_roundings(root):
+    """The second exception of the f64 parity rule (oracle/parity.py): the oracle measures, on the sample
+    itself, by how much the path multiplies an error of one of its directions.  Flat, diffuse geometry
+    does not (the Cornell box: far below the 4 400 at which 1024 ulps reach the 1e-9 bar, so nothing
+    there is ever excused); a path over the smoothly shaded furniture of room.obj does -- a hundredfold
+    per bounce -- and only there may a difference beyond the bar pass, up to 1024 ulps times the factor."""
+    from oracle import parity
+    sc = scene_io.load_conf(os.path.join(root, "config/cbox.conf"), root_dir=root, width=64, height=64, spp=8)
+    O = oracle.Oracle(sc, seed=13)
+    amps = [O.amplification(x, y, 0) for x, y in ((30, 40), (10, 50), (50, 12), (32, 32))]
+    assert all(0.0 <= a < 1000.0 for a in amps), amps
+    rgb = O.trace_sample(30, 40, 0)[0]
+    assert parity.match_sample(rgb + 2e-9, O, 30, 40, 0)[0] == "unmatched"
+    room = scene_io.load_conf(os.path.join(root, "config/room.conf"), root_dir=root, width=3840, height=2160, spp=1)
+    R = oracle.Oracle(room, seed=13)
+    x, y = 210, 567                          # a five-bounce path over curved furniture (found by tools/prove_frame.py)
+    amp = R.amplification(x, y, 0)
+    assert 5e4 < amp < 5e5, amp
+    assert abs(R.amplification(x, y, 0, eps=1e-11) / amp - 1.0) < 0.05   # a derivative, not an artefact of the step
+    rgb = R.trace_sample(x, y, 0)[0]
+    status, _, detail = parity.match_sample(rgb + 2.8e-9, R, x, y, 0)    # what the GPU differs by on this sample
+    assert status == "amplified" and detail["amplification"] == amp
+    assert parity.match_sample(rgb + 1e-6, R, x, y, 0)[0] == "unmatched"  # 40 times the allowance: a bug, not a rounding
+    assert R.amplification(100, 100, 0) < 100.0                          # a wall: the same scene, an ordinary path
+    # the physically based estimator has no such probe: nothing is excused there
+    F = oracle.Oracle(sc, seed=13, estimator="fast")
+    assert F.amplification(30, 40, 0) is None

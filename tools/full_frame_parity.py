@@ -83,10 +83,11 @@ def main():
 
         r = parity.prove_pixels(c, O, [(int(y), int(x)) for y, x in pick], range(a.spp), seed=13, render_row=render_row)
         proven = r["proven_ties"]
-        unexplained = len(pick) - proven
+        unexplained = len(pick) - proven - r["amplified"]
         for y, x, smp, detail in r["unmatched"][:20]:
             print("pixel (%d, %d) sample %d: NOT MATCHED %s" % (y, x, smp, detail), file=sys.stderr, flush=True)
-        rec.update(tie_samples=r["tie_samples"], unmatched_samples=len(r["unmatched"]), pixels_no_sample_differs=r["no_sample_differs"])
+        rec.update(tie_samples=r["tie_samples"], unmatched_samples=len(r["unmatched"]), pixels_no_sample_differs=r["no_sample_differs"],
+                   amplified_roundings=r["amplified"], amplifications=[round(v) for v in r["amplifications"]])
     rec.update(pixels_put_to_the_proof=int(len(pick)), proven_ties=proven, not_explained=unexplained)
     print(json.dumps(rec), flush=True)
     return 0 if unexplained == 0 else 1
