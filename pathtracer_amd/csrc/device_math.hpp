@@ -398,8 +398,11 @@ __device__ __forceinline__ R square_light_sample(const R *__restrict__ L, V3<R> 
 // sphere light: the returned ray starts at the shaded point itself (so it is never shadowed) and
 // points from the centre towards the point; only the cone pdf survives.  Inside the sphere a
 // uniform surface point is used (3 draws).
+// The three draws (dimensions 4 l, 4 l + 1, 4 l + 2 of the bounce) are only made inside the sphere:
+// outside it the sample is a function of the geometry alone, and a draw is two 64-bit multiplies.
 template <class R>
-__device__ __forceinline__ R sphere_light_sample(const R *__restrict__ L, V3<R> ref, R xi1, R xi2, R xi3, V3<R> &ro, V3<R> &rd)
+__device__ __forceinline__ R sphere_light_sample(const R *__restrict__ L, V3<R> ref, uint64_t key, uint32_t sample, uint32_t bounce, int l, V3<R> &ro,
+                                                 V3<R> &rd)
 {
 #pragma clang fp contract(fast) // shading side: fused multiply-adds allowed
     const R pi = Consts<R>::pi;
@@ -415,6 +418,8 @@ __device__ __forceinline__ R sphere_light_sample(const R *__restrict__ L, V3<R> 
         rd = -to_light;
         return (R(1) + sqrt(R(1) - x2)) / (R(2) * pi * x2);
     }
+    const R xi1 = rng_draw<R>(key, sample, bounce, 4 * l + 0), xi2 = rng_draw<R>(key, sample, bounce, 4 * l + 1);
+    const R xi3 = rng_draw<R>(key, sample, bounce, 4 * l + 2);
     V3<R> u = fast_normalized(V3<R>{xi1 - R(0.5), xi2 - R(0.5), xi3 - R(0.5)});
     V3<R> lp = u * rad + C;
     rd = fast_normalized(ref - lp);

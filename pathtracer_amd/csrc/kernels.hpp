@@ -1433,13 +1433,15 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                     L = S.lights + (size_t)l * LIGHT_STRIDE;
                 V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
                 R pdf;
-                const R x1 = rng_draw<R>(key, sample, bounce, 4 * l + 0);
-                const R x2 = rng_draw<R>(key, sample, bounce, 4 * l + 1);
                 const bool square = SQ1 || (LIGHTS != 0 && L[0] == R(0)); // LIGHTS == 0: the scene has no square light
+                // a square light takes two draws; a sphere light makes its own, and only when the point is inside it
+                R x1 = R(0), x2 = R(0);
+                if (square)
+                    x1 = rng_draw<R>(key, sample, bounce, 4 * l + 0), x2 = rng_draw<R>(key, sample, bounce, 4 * l + 1);
                 if (square)
                     pdf = square_light_sample(L, p, x1, x2, ro, rd);
                 else
-                    pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bounce, 4 * l + 2), ro, rd);
+                    pdf = sphere_light_sample(L, p, key, uint32_t(sample), uint32_t(bounce), l, ro, rd);
                 if (pdf < R(1e-10))
                     continue;
                 const R cn = dot(nrm, -rd);

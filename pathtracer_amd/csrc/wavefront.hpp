@@ -376,14 +376,16 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK, PTX_WF_SHADE_WAVES)
             {
                 const R *L = S.lights + (size_t)l * LIGHT_STRIDE;
                 V3<R> ro = {R(0), R(0), R(0)}, rd = {R(0), R(0), R(0)};
-                const R x1 = rng_draw<R>(key, sample, bnc, 4 * l + 0);
-                const R x2 = rng_draw<R>(key, sample, bnc, 4 * l + 1);
                 const bool square = SQ && L[0] == R(0);
+                // a square light takes two draws; a sphere light makes its own, and only when the point is inside it
+                R x1 = R(0), x2 = R(0);
+                if (square)
+                    x1 = rng_draw<R>(key, sample, bnc, 4 * l + 0), x2 = rng_draw<R>(key, sample, bnc, 4 * l + 1);
                 R pdf;
                 if (square)
                     pdf = square_light_sample(L, p, x1, x2, ro, rd);
                 else
-                    pdf = sphere_light_sample(L, p, x1, x2, rng_draw<R>(key, sample, bnc, 4 * l + 2), ro, rd);
+                    pdf = sphere_light_sample(L, p, key, uint32_t(sample), uint32_t(bnc), l, ro, rd);
                 if (pdf < R(1e-10))
                     continue;
                 const R cn = dot(nrm, -rd);
