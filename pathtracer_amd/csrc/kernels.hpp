@@ -1570,14 +1570,15 @@ __global__ void __launch_bounds__(BLOCK, BRUTE ? 4 : 3) k_trace_f32(DScene<float
     trace_body<float, BRUTE, TAB, LIGHTS>(S, cam, B, st, chunk);
 }
 // the physically based estimator on the same tracer (LIGHTS: 1 -- one light, its tests parked;
-// 2 -- tests in place; 0 -- no light)
+// 2 -- tests in place; 0 -- no light).  With the tests parked the all-triangles f64 kernel fits three
+// waves per SIMD (168 registers, 64 bytes of spills); the other variants would spill 112 to 272 bytes.
 template <bool BRUTE, bool TAB, int LIGHTS>
-__global__ void __launch_bounds__(BLOCK, 2) k_trace_fast_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
+__global__ void __launch_bounds__(BLOCK, (BRUTE && LIGHTS == 1) ? 3 : 2) k_trace_fast_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
 {
     trace_body<double, BRUTE, TAB, LIGHTS, true>(S, cam, B, st, chunk);
 }
 template <bool BRUTE, bool TAB, int LIGHTS>
-__global__ void __launch_bounds__(BLOCK, 3) k_trace_fast_f32(DScene<float> S, DCamera cam, DBatch B, DState<float> st, int chunk)
+__global__ void __launch_bounds__(BLOCK, (BRUTE && LIGHTS == 1) ? 4 : 3) k_trace_fast_f32(DScene<float> S, DCamera cam, DBatch B, DState<float> st, int chunk)
 {
     trace_body<float, BRUTE, TAB, LIGHTS, true>(S, cam, B, st, chunk);
 }
