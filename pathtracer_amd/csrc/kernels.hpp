@@ -1557,10 +1557,11 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
 }
 
 // The two precisions are separate kernels because their register budgets differ: the f64 tracer
-// runs 2 waves per SIMD (up to 256 vector registers) -- 3 (168 registers) when the visibility
-// tests are queued, which takes their live range out of the shading code -- the f32 tracer 4 (128).
+// runs 3 waves per SIMD (168 vector registers; with in-place visibility tests it would take 174 left
+// alone, and holding it to 168 costs no spill on LDS-resident scenes and 16 to 176 bytes on BVH ones:
+// cbox_cube 2 680 -> 3 232 Mpaths/s), the f32 tracer 4 (128) or whatever its LDS allows.
 template <bool BRUTE, bool TAB, int LIGHTS>
-__global__ void __launch_bounds__(BLOCK, (LIGHTS == 1 || !BRUTE) ? 3 : 2) k_trace_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
+__global__ void __launch_bounds__(BLOCK, 3) k_trace_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
 {
     trace_body<double, BRUTE, TAB, LIGHTS>(S, cam, B, st, chunk);
 }
@@ -1570,10 +1571,11 @@ __global__ void __launch_bounds__(BLOCK, BRUTE ? 4 : 3) k_trace_f32(DScene<float
     trace_body<float, BRUTE, TAB, LIGHTS>(S, cam, B, st, chunk);
 }
 // the physically based estimator on the same tracer (LIGHTS: 1 -- one light, its tests parked;
-// 2 -- tests in place; 0 -- no light).  With the tests parked the all-triangles f64 kernel fits three
-// waves per SIMD (168 registers, 64 bytes of spills); the other variants would spill 112 to 272 bytes.
+// 2 -- tests in place; 0 -- no light).  On LDS-resident scenes the f64 kernel is held to three waves
+// per SIMD (168 registers; 64 bytes of spills with parked tests, 112 with tests in place: cbox 2 793 ->
+// 3 115, cbox_cube 2 053 -> 2 207 Mpaths/s); the BVH variants would spill 272 bytes and stay at two.
 template <bool BRUTE, bool TAB, int LIGHTS>
-__global__ void __launch_bounds__(BLOCK, (BRUTE && LIGHTS == 1) ? 3 : 2) k_trace_fast_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
+__global__ void __launch_bounds__(BLOCK, BRUTE ? 3 : 2) k_trace_fast_f64(DScene<double> S, DCamera cam, DBatch B, DState<double> st, int chunk)
 {
     trace_body<double, BRUTE, TAB, LIGHTS, true>(S, cam, B, st, chunk);
 }

@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
-"""Registers, scratch and LDS of every kernel: parses the remarks of
-hipcc -Rpass-analysis=kernel-resource-usage (stderr of a compile) given as a file."""
-import re, sys
-cur = {}
-rows = []
-for line in open(sys.argv[1]):
-    m = re.search(r"remark: .*?(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\S+)", line)
-    if not m:
-        continue
-    k, v = m.group(1), m.group(2)
-    if k == "Function Name":
-        cur = {"name": v}
-        rows.append(cur)
-    else:
-        cur[k.split(" ")[0]] = v
-for r in rows:
-    if len(sys.argv) > 2 and sys.argv[2] not in r["name"]:
-        continue
-    print("%-70s vgpr %4s agpr %3s sgpr %4s scratch %5s occ %2s lds %6s" % (r["name"][:70], r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"), r.get("ScratchSize"), r.get("Occupancy"), r.get("LDS")))
+"""Vector registers, LDS and scratch of every kernel of the library, from its gfx950 assembly
+(hipcc ... --cuda-device-only -S context.hip -o context.s with the Makefile's flags), and the waves per
+SIMD the registers allow (512 per lane and SIMD).   python tools/kernel_resources.py context.s"""
+import re
+import subprocess
+import sys
+
+
+def main():
+    txt = open(sys.argv[1]).read()
+    rows = []
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)\n(.*?)\.end_amdhsa_kernel", txt, re.S):
+        body = m.group(2)
+        get = lambda k: int(re.search(k + r" (\d+)", body).group(1))
+        rows.append((m.group(1), get(r"\.amdhsa_next_free_vgpr"), get(r"\.amdhsa_group_segment_fixed_size"), get(r"\.amdhsa_private_segment_fixed_size")))
+    names = subprocess.run(["c++filt"] + [r[0] for r in rows], capture_output=True, text=True).stdout.strip().split("\n")
+    for (_, vgpr, lds, scratch), name in zip(rows, names):
+        name = name.split("(")[0].replace("ptx::", "").replace("void ", "")
+        print("%-56s vgpr %3d  lds %6d  scratch %4d  waves per SIMD by registers %d" % (name[:56], vgpr, lds, scratch, min(8, 512 // max(vgpr, 1))))
+
+
+if __name__ == "__main__":
+    main()
