@@ -25,7 +25,7 @@ int main(int argc, char **argv)
                     "        several GPUs of this node: [--gpus N | --devices ID,ID,...] [--scheme bands|samples] "
                     "[--exchange rccl|peer]\n"
                     "        a part of the frame for later merging (python -m pathtracer_amd.image --merge): "
-                    "--dump-partial FILE [--rows A:B] [--samples A:B]\n");
+                    "--dump-partial FILE [--rows A:B] [--samples A:B] [--resume: skip the part if FILE already holds it]\n");
         return 1;
     }
     ptx_overrides ov;
@@ -36,6 +36,7 @@ int main(int argc, char **argv)
     ro.seed = 13;
     std::string out_path, root, dump_path;
     int rows_a = 0, rows_b = 0, smp_a = 0, smp_b = 0; // --rows A:B, --samples A:B (half-open; 0:0 = all)
+    bool resume = false;                              // --resume: a part file that is already complete is left alone
     auto range = [](const char *txt, int &a, int &b) {
         const char *colon = std::strchr(txt, ':');
         a = std::atoi(txt);
@@ -96,6 +97,8 @@ int main(int argc, char **argv)
             ro.estimator = std::string(next()) == "fast" ? PTX_ESTIMATOR_FAST : PTX_ESTIMATOR_REFERENCE;
         else if (a == "--dump-partial")
             dump_path = next();
+        else if (a == "--resume")
+            resume = true;
         else if (a == "--rows" || a == "--samples")
         {
             int &lo = a == "--rows" ? rows_a : smp_a, &hi = a == "--rows" ? rows_b : smp_b;
@@ -137,6 +140,37 @@ int main(int argc, char **argv)
             smp_a = 0, smp_b = info.spp;
         ro.row_begin = rows_a, ro.row_end = rows_b;
         ro.sample_offset = smp_a, ro.spp = smp_b - smp_a, ro.spp_total = info.spp;
+        if (resume)
+        {
+            // a run that was cut short starts again with the same command lines: a part whose file is there,
+            // names this very piece of this very frame and has its full length is not rendered again
+            const int32_t want[12] = {info.width, info.height, info.spp, rows_a, rows_b, smp_a, smp_b, ro.mode, ro.estimator, info.depth, 0, 0};
+            if (FILE *f = std::fopen(dump_path.c_str(), "rb"))
+            {
+                char magic[8];
+                int32_t head[12];
+                uint64_t seed = 0;
+                bool same = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "PTXPART1", 8) == 0 && std::fread(head, sizeof(head), 1, f) == 1 &&
+                            std::memcmp(head, want, sizeof(want)) == 0 && std::fread(&seed, 8, 1, f) == 1 && seed == ro.seed;
+                if (same)
+                {
+                    std::fseek(f, 0, SEEK_END);
+                    same = std::ftell(f) == 64 + static_cast<long>(rows_b - rows_a) * info.width * 3 * 8;
+                }
+                std::fclose(f);
+                if (same)
+                {
+                    std::printf("[debug] %s already holds rows %d:%d, samples %d:%d: nothing to do\n", dump_path.c_str(), rows_a, rows_b, smp_a, smp_b);
+                    ptx_scene_destroy(scene);
+                    return 0;
+                }
+            }
+        }
+    }
+    else if (resume)
+    {
+        std::printf("[error] --resume goes with --dump-partial\n");
+        return 1;
     }
     if (devices.empty())
         devices.push_back(gpu);

@@ -127,3 +127,15 @@ def test_dumped_parts_merge_to_the_one_piece_ppm(root, tmp_path):
     assert p.returncode == 1 and "[error]" in p.stdout
     p = subprocess.run(base + ["--rows", "0:10"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert p.returncode == 1 and "--dump-partial" in p.stdout
+    # --resume: the same command line again leaves a complete part alone, renders a missing, a truncated or a foreign one
+    before = os.stat(parts["top"]).st_mtime_ns
+    assert "nothing to do" in run(["--dump-partial", parts["top"], "--rows", "0:24", "--resume"])
+    assert os.stat(parts["top"]).st_mtime_ns == before
+    blob = open(parts["top"], "rb").read()
+    open(parts["top"], "wb").write(blob[:-8])                                    # cut short
+    assert "nothing to do" not in run(["--dump-partial", parts["top"], "--rows", "0:24", "--resume"])
+    assert open(parts["top"], "rb").read() == blob                               # and whole again, the same bytes
+    assert "nothing to do" not in run(["--dump-partial", parts["top"], "--rows", "0:20", "--resume"])   # another piece: rendered
+    assert "nothing to do" not in run(["--dump-partial", str(tmp_path / "new.part"), "--rows", "0:24", "--resume"])
+    p = subprocess.run(base + ["--resume"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert p.returncode == 1 and "--resume" in p.stdout
