@@ -38,7 +38,7 @@ template <class R> struct WfQueue
 // pid[l * segments ...], its length count[WF_TEST_COUNTS + l], the segment count count[WF_TEST_SEGS].
 // The any-hit launch walks the lists one after the other, so no lane ever takes an empty slot and
 // neighbouring lanes test neighbouring segments against the same light.
-constexpr int WF_MAX_LIGHTS = 12, WF_TEST_SEGS = 2, WF_TEST_COUNTS = 4;
+constexpr int WF_MAX_LIGHTS = 32, WF_TEST_SEGS = 2, WF_TEST_COUNTS = 4; // a segment names its tests in a 32-bit set
 constexpr int WF_QUEUE_HEADER_WORDS = WF_TEST_COUNTS + WF_MAX_LIGHTS;
 
 // a wave runs a triangle step (exact test in R) instead of a node step (four f32 slab tests) when

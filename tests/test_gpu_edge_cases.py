@@ -246,6 +246,61 @@ def test_ring_tracer_with_one_square_light_among_sphere_lights(mis, position, bv
     assert_f64_parity(img, oimg, st, ost)
 
 
+def test_wavefront_tracer_with_more_than_twelve_lights(mis):
+    """Twenty lights, six of them square.  The physically based estimator tests every light: its
+    visibility tests go through the wavefront tracer's test queue (a slot per light and segment, the
+    tests named in dense lists per light; up to 32 lights: a segment marks its tests in a 32-bit set) and
+    meet the oracle running that estimator.  The reference's estimator tests the squares only and stays
+    on the ring tracer beyond twelve lights (every light would take a slot): equal to the lane tracer bit
+    for bit, as ever."""
+    ref = copy.deepcopy(mis)
+    lo, hi = ref.verts.reshape(-1, 3).min(0), ref.verts.reshape(-1, 3).max(0)
+    rng = np.random.default_rng(11)
+    lights = list(ref.lights)
+    for k in range(15):
+        L = np.zeros(ref.lights.shape[1])
+        L[1:4] = rng.uniform(0.5, 4.0, 3)
+        if k % 5 < 2:                                                # a small square under the top of the scene
+            x, z = rng.uniform(lo[[0, 2]] + 0.1 * (hi - lo)[[0, 2]], hi[[0, 2]] - 0.2 * (hi - lo)[[0, 2]])
+            e, y = 0.08 * (hi - lo)[[0, 2]], hi[1] - rng.uniform(0.02, 0.1) * (hi[1] - lo[1])
+            L[4:16] = np.array([[x, y, z], [x + e[0], y, z], [x + e[0], y, z + e[1]], [x, y, z + e[1]]]).ravel()
+        else:
+            L[0] = 1.0
+            L[4:7] = rng.uniform(lo, hi)
+            L[7] = rng.uniform(0.02, 0.1) * float((hi - lo).max())
+        lights.insert(int(rng.integers(0, len(lights) + 1)), L)
+    ref.lights = np.array(lights)
+    assert len(ref.lights) == 20 and int((ref.lights[:, 0] == 0).sum()) == 6
+    TRACER.clear()
+    img, st, oimg, ost, c = render_both(ref)
+    assert "k_trace_rings" in c.last_kernel(), c.last_kernel()
+    assert st["shadow_rays"] > 0
+    assert_f64_parity(img, oimg, st, ost)
+    lane = pt.Context(0)
+    lane.set_option("bvh_rings", 0)
+    lane.build_accel(gpu_scene(ref))
+    limg, lst = lane.render(mode="f64", seed=13)
+    assert np.array_equal(limg, img)
+    assert (lst["segments"], lst["shadow_rays"], lst["records"]) == (st["segments"], st["shadow_rays"], st["records"])
+    # the physically based estimator: every light is tested, through the wavefront tracer's test queue
+    F = oracle.Oracle(ref, seed=13, estimator="fast")
+    fimg, fst = c.render(mode="f64", seed=13, estimator="fast")
+    assert "k_wf_shade_fast" in c.last_kernel(), c.last_kernel()
+    foimg, fost = F.render(stats=True)
+    scale = np.maximum(1.0, np.abs(foimg).max(axis=-1, keepdims=True))
+    _assert_f64_parity(fimg / scale, foimg / scale, fst, fost, depth=ref.depth, ctx=c, O=F, render_kw=dict(estimator="fast"))
+    assert fst["shadow_rays"] > st["shadow_rays"]
+    lfimg, lfst = lane.render(mode="f64", seed=13, estimator="fast")
+    assert np.abs(lfimg - fimg).max() <= 1e-9 * max(1.0, float(np.abs(fimg).max()))
+    assert (lfst["segments"], lfst["shadow_rays"], lfst["records"]) == (fst["segments"], fst["shadow_rays"], fst["records"])
+    # thirty-three lights are one too many for the set: such a scene stays on the lane tracer
+    ref.lights = np.array(list(ref.lights) + [ref.lights[-1]] * 13)
+    c33 = pt.Context(0)
+    c33.build_accel(gpu_scene(ref))
+    c33.render(mode="f64", seed=13, spp=1, estimator="fast")
+    assert "k_wf_" not in c33.last_kernel(), c33.last_kernel()
+
+
 def test_ring_tracer_with_several_square_lights(mis, bvh_tracer):
     """Every square light with a valid sample costs the hit one more trip round the rings; results
     and test counts are those of the lane tracer and of the oracle."""
