@@ -566,7 +566,8 @@ __device__ __forceinline__ bool bvh_step(const DScene<R> &S, V3<R> o, V3<R> d, T
 // so that its bounds are in the units of the winner's distance |p - o|; the exact test runs on the
 // ray (o, d) as given, whatever the length of d (the tracer's rays are unit length: du = d).
 template <class R, bool BRUTE>
-__device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d, V3<R> du, V3<R> &pt, int *stk, int skip = -1)
+__device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d, V3<R> du, V3<R> &pt, int *stk, int skip = -1,
+                                           uint32_t *n_exact = nullptr) // n_exact (diagnostic build): exact tests this lane ran
 {
     R best = Consts<R>::big;
     int target = -1;
@@ -579,6 +580,8 @@ __device__ __forceinline__ int closest_hit(const DScene<R> &S, V3<R> o, V3<R> d,
             prefilter_mask<true>(S.tri_pq, S.n_recs, S.pq_smax, o, du, float(self_eps) * 0.9f, __builtin_inff(), 0xFFFFFFFFu, near_rec);
         mask = drop_own_plane(mask, L, skip, du);
         auto exact = [&](int bit) {
+            if (n_exact)
+                ++*n_exact;
             const int f = L->rec_tri[bit];
             R t;
             if (f >= 0 && tri_test(L->tri + f * 12, o, d, t))
@@ -877,10 +880,26 @@ struct DoneQueue
         ph_t[k] += now_ - ph_last, ph_n[k]++;                              \
         ph_last = now_;                                                    \
     } while (0)
+// lane occupancy of a part: `work` of this lane (0 / 1, or a trip count) against the longest of the wave
+#define PTX_PHASE_LANES(k, work)                                                         \
+    do                                                                                   \
+    {                                                                                    \
+        uint32_t w_ = uint32_t(work), mx_ = w_, sm_ = w_;                                \
+        for (int off_ = 32; off_ > 0; off_ >>= 1)                                        \
+        {                                                                                \
+            mx_ = max(mx_, uint32_t(__shfl_xor(int(mx_), off_, 64)));                    \
+            sm_ += uint32_t(__shfl_xor(int(sm_), off_, 64));                             \
+        }                                                                                \
+        ph_lane_work[k] += sm_, ph_lane_room[k] += 64ull * mx_;                          \
+    } while (0)
 #else
 #define PTX_PHASE_END(k) \
     do                   \
     {                    \
+    } while (0)
+#define PTX_PHASE_LANES(k, work) \
+    do                           \
+    {                            \
     } while (0)
 #endif
 template <class R, bool BRUTE, bool TAB, int LIGHTS, bool FAST = false>
@@ -960,6 +979,9 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
 #ifdef PTX_PHASE_TIMING
     unsigned long long ph_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last = __builtin_readcyclecounter();
     uint32_t ph_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // lane work done / lane slots offered (64 x the longest lane) in: 0 path starts, 1 closest hit (lanes alive),
+    // 2 shading, 3 visibility passes, 4 resolve folds, 5 exact triangle tests
+    unsigned long long ph_lane_work[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_lane_room[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     auto drain = [&](uint32_t n) {
         PTX_PHASE_END(2);
@@ -1009,6 +1031,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             sq_head = (sq_head + n) % ShadowQueue<R>::CAP;
             sq_count -= n;
             sq_drained += n;
+            PTX_PHASE_LANES(3, uint32_t(lane) < n ? 1u : 0u);
         }
         PTX_PHASE_END(3);
     };
@@ -1049,6 +1072,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         int wlen = len; // longest stack of the wave: the loop below has a wave-uniform trip count
         for (int off = 32; off > 0; off >>= 1)
             wlen = max(wlen, __shfl_xor(wlen, off, 64));
+        PTX_PHASE_LANES(4, len);
         const R *rec = record_at(st, g, rslot, depth, 0u);
         // four levels per trip: their loads are issued together, so the wave waits for the memory
         // system once per four bounces instead of once per bounce
@@ -1177,6 +1201,8 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
             // the lanes that start a path now each take a record slot off the wave's stack
             const bool starts = !alive && blk_pos + uint32_t(__popcll(idle & lt_mask)) < blk_cnt;
             const unsigned long long sm = __ballot(starts);
+            if (sm != 0ull)
+                PTX_PHASE_LANES(0, starts ? 1u : 0u);
             if (starts)
                 slot = free_slot[free_count - 1u - uint32_t(__popcll(sm & lt_mask))];
             free_count -= uint32_t(__popcll(sm));
@@ -1215,11 +1241,21 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         V3<R> p = {R(0), R(0), R(0)};
         int hit_k = -1;
         const R *m = nullptr; // the address space (LDS or global) is fixed at compile time
+#ifdef PTX_PHASE_TIMING
+        uint32_t lane_exact = 0;
+        PTX_PHASE_LANES(1, (BRUTE ? alive : (alive && trav_done)) ? 1u : 0u);
+#endif
         if (BRUTE ? alive : (alive && trav_done))
         {
             n_seg++;
             if constexpr (BRUTE)
+            {
+#ifdef PTX_PHASE_TIMING
+                hit_k = closest_hit<R, BRUTE>(S, o, d, d, p, stk, prim, &lane_exact);
+#else
                 hit_k = closest_hit<R, BRUTE>(S, o, d, d, p, stk, prim);
+#endif
+            }
             else
                 hit_k = T.target, p = o + T.best_t * d;
             int mat_id = -1;
@@ -1276,6 +1312,10 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 shaded = true;
         }
 
+#ifdef PTX_PHASE_TIMING
+        PTX_PHASE_LANES(5, lane_exact);
+        PTX_PHASE_LANES(2, shaded ? 1u : 0u);
+#endif
         PTX_PHASE_END(1);
         bool park = false; // this lane has a visibility test for the queue
         R park_x1 = R(0), park_x2 = R(0);
@@ -1529,8 +1569,13 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
         resolve(dq_count < 64u ? dq_count : 64u);
 #ifdef PTX_PHASE_TIMING
     if (lane == 0 && g % 500 == 3)
+    {
         printf("wave %d cycles: start %llu (%u) hit %llu (%u) shade %llu (%u) tests %llu (%u) resolve %llu (%u) queues %llu (%u)\n", g, ph_t[0], ph_n[0],
                ph_t[1], ph_n[1], ph_t[2], ph_n[2], ph_t[3], ph_n[3], ph_t[4], ph_n[4], ph_t[5], ph_n[5]);
+        printf("wave %d lanes: start %llu/%llu hit %llu/%llu shade %llu/%llu tests %llu/%llu resolve %llu/%llu exact %llu/%llu\n", g, ph_lane_work[0],
+               ph_lane_room[0], ph_lane_work[1], ph_lane_room[1], ph_lane_work[2], ph_lane_room[2], ph_lane_work[3], ph_lane_room[3], ph_lane_work[4],
+               ph_lane_room[4], ph_lane_work[5], ph_lane_room[5]);
+    }
 #endif
     // per-wave statistics (the wave owns its row)
     for (int off = 32; off > 0; off >>= 1)
