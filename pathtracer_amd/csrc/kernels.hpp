@@ -823,6 +823,7 @@ template <class R> struct RayBlock
 {
     R d[3][64];
     uint64_t key[64];
+    uint32_t sample[64]; // sample index of the path (its id divided by the pixels of the batch: one division on full lanes)
 };
 
 // Pending visibility tests of one wave (ring buffer in LDS).  Only part of the lanes have a valid
@@ -1192,6 +1193,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 primary_ray<R>(cam, col, row, ro, rd);
                 blk.d[0][lane] = rd.x, blk.d[1][lane] = rd.y, blk.d[2][lane] = rd.z;
                 blk.key[lane] = rng_pixel_key(B.seed, uint32_t(row) * uint32_t(B.image_width) + uint32_t(col));
+                blk.sample[lane] = uint32_t(B.sample0) + id / n_pix;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1216,7 +1218,7 @@ __device__ __forceinline__ void trace_body(const DScene<R> &S, const DCamera &ca
                 o = cam_pos;
                 d = {blk.d[0][e], blk.d[1][e], blk.d[2][e]};
                 key = blk.key[e];
-                sample = uint32_t(B.sample0) + pid / n_pix;
+                sample = blk.sample[e];
                 bounce = 0, prim = -1;
                 alive = true;
                 if constexpr (FAST)
